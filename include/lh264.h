@@ -1,0 +1,192 @@
+/*
+ * lh264.h - C ABI of the MI355X-native decode-reconstruct hot path.
+ *
+ * This is the FINE drop-in boundary of the reference:
+ * the reference reconstructs one slice at a time on the CPU through
+ *     WelsTargetSliceConstruction(ctx)      codec/decoder/core/src/decode_slice.cpp:110-206
+ *       -> WelsTargetMbConstruction         decode_slice.cpp:353-373
+ *       -> WelsDeblockingFilterSlice        codec/decoder/core/src/deblocking.cpp:872-934
+ *     ExpandReferencingPicture              codec/common/src/expand_pic.cpp:145-174
+ * reading the per-macroblock arrays of SDqLayer (codec/decoder/core/inc/dec_frame.h:60-97).
+ * Here the same per-macroblock state is handed over as flat records
+ * (lh264_mb_t + 384 int16 coefficients per macroblock) and whole batches of
+ * frames are reconstructed on the GPU by hand-written gfx950 kernels.
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * Every pointer named *_dev is a device (HBM) address.
+ */
+#ifndef LH264_H_
+#define LH264_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LH264_ABI_VERSION 1
+
+/* ---- macroblock types: the reference's own flag values (codec/common/inc/wels_common_defs.h:264-281) */
+#define LH264_MB_I4x4      0x0001
+#define LH264_MB_I16x16    0x0002
+#define LH264_MB_I8x8      0x0004
+#define LH264_MB_P16x16    0x0008
+#define LH264_MB_P16x8     0x0010
+#define LH264_MB_P8x16     0x0020
+#define LH264_MB_P8x8      0x0040
+#define LH264_MB_P8x8REF0  0x0080
+#define LH264_MB_SKIP      0x0100
+#define LH264_MB_IPCM      0x0200
+#define LH264_MB_INTRA     (LH264_MB_I4x4 | LH264_MB_I16x16 | LH264_MB_I8x8 | LH264_MB_IPCM)
+#define LH264_MB_INTER     (LH264_MB_P16x16 | LH264_MB_P16x8 | LH264_MB_P8x16 | LH264_MB_P8x8 | LH264_MB_P8x8REF0 | LH264_MB_SKIP)
+#define LH264_SUB_8x8 1
+#define LH264_SUB_8x4 2
+#define LH264_SUB_4x8 4
+#define LH264_SUB_4x4 8
+
+/* final (availability-resolved) intra modes, wels_common_defs.h:303-342 */
+enum { LH264_I4_V = 0, LH264_I4_H, LH264_I4_DC, LH264_I4_DDL, LH264_I4_DDR, LH264_I4_VR, LH264_I4_HD, LH264_I4_VL,
+       LH264_I4_HU, LH264_I4_DC_L, LH264_I4_DC_T, LH264_I4_DC_128, LH264_I4_DDL_TOP, LH264_I4_VL_TOP };
+enum { LH264_I16_V = 0, LH264_I16_H, LH264_I16_DC, LH264_I16_P, LH264_I16_DC_L, LH264_I16_DC_T, LH264_I16_DC_128 };
+enum { LH264_C_DC = 0, LH264_C_H, LH264_C_V, LH264_C_P, LH264_C_DC_L, LH264_C_DC_T, LH264_C_DC_128 };
+
+#define LH264_MBF_T8x8   0x01   /* transform_size_8x8_flag (pTransformSize8x8Flag) */
+#define LH264_MBF_PCM_IN_COEFF 0x02 /* I_PCM: the 384 samples are carried in the coefficient slot (low byte of each int16) */
+
+/* intra_avail bits = pIntraNxNAvailFlag (decode_slice.cpp:567-569, rec_mb.cpp:88-96) */
+#define LH264_AVAIL_T  0x1
+#define LH264_AVAIL_TL 0x2
+#define LH264_AVAIL_L  0x4
+#define LH264_AVAIL_TR 0x8
+
+#define LH264_MB_COEFFS 384     /* MB_COEFF_LIST_SIZE, codec/common/inc/wels_const_common.h:55 */
+#define LH264_PAD_LUMA   32     /* PADDING_LENGTH, expand_pic.h:49 */
+#define LH264_PAD_CHROMA 16
+#define LH264_MAX_REFS   16
+
+/*
+ * One macroblock, 128 bytes. Field meaning == the SDqLayer array of the same
+ * name at index iMbXy (dec_frame.h:60-97) at the moment the reference enters
+ * WelsTargetMbConstruction, i.e. after parsing, before any in-place transform.
+ */
+typedef struct lh264_mb {
+  uint16_t mb_type;         /* pMbType                                                   */
+  uint8_t  cbp;             /* pCbp: luma bits 0-3, chroma (0..2) << 4                   */
+  uint8_t  qp_y;            /* pLumaQp                                                   */
+  uint8_t  qp_c[2];         /* pChromaQp[2] (Cb, Cr)                                     */
+  uint8_t  flags;           /* LH264_MBF_*                                               */
+  uint8_t  intra_avail;     /* pIntraNxNAvailFlag (only I8x8 reads it)                   */
+  int8_t   intra_mode[16];  /* pIntra4x4FinalMode[16] (index = raster 4x4 block; I8x8 uses the
+                               top-left 4x4 of each 8x8); I16x16: [0] = pIntraPredMode[7] */
+  int8_t   chroma_mode;     /* pChromaPredMode                                           */
+  uint8_t  reserved0;
+  uint16_t slice_id;        /* index into the frame's lh264_slice_t table (pSliceIdc)    */
+  uint8_t  sub_type[4];     /* pSubMbType[4]                                             */
+  int8_t   ref_idx[4];      /* pRefIndex[LIST_0] of the four 8x8 quadrants               */
+  uint8_t  nzc[24];         /* pNzc[24], the reference's raster layout (common_tables.cpp:39-47),
+                               as left by the parser (the kernels only test != 0)        */
+  int16_t  mv[16][2];       /* pMv[LIST_0][16][2], raster 4x4 blocks, quarter-pel        */
+  uint8_t  reserved1[4];
+} lh264_mb_t;
+
+/* One slice of a frame (the SSliceHeader fields the hot path reads). */
+typedef struct lh264_slice {
+  int32_t  first_mb;            /* iFirstMbInSlice                                        */
+  int32_t  n_mbs;               /* iTotalMbInCurSlice (consecutive raster MBs; no FMO)    */
+  uint8_t  slice_type;          /* 0 = P, 2 = I (EWelsSliceType)                          */
+  uint8_t  deblock_idc;         /* uiDisableDeblockingFilterIdc (0,1,2)                   */
+  int8_t   alpha_c0_offset;     /* iSliceAlphaC0Offset (already x2, as the reference keeps it) */
+  int8_t   beta_offset;         /* iSliceBetaOffset                                       */
+  uint8_t  weighted_pred;       /* bUseWeightPredictionFlag                               */
+  uint8_t  luma_log2_denom;     /* uiLumaLog2WeightDenom                                  */
+  uint8_t  chroma_log2_denom;   /* uiChromaLog2WeightDenom                                */
+  uint8_t  n_refs;              /* uiRefCount[0]                                          */
+  int16_t  luma_weight[LH264_MAX_REFS];
+  int16_t  luma_offset[LH264_MAX_REFS];
+  int16_t  chroma_weight[LH264_MAX_REFS][2];
+  int16_t  chroma_offset[LH264_MAX_REFS][2];
+  int8_t   ref_slot[LH264_MAX_REFS]; /* ref_idx -> index into lh264_frame_job_t.ref (sRefPic.pRefList[LIST_0]) */
+  uint8_t  luma_dc_weight;      /* Intra-Y 4x4 scaling-list entry [0] (16 = flat): feeds kiQMul of
+                                   WelsLumaDcDequantIdct, decode_slice.cpp:272                      */
+  uint8_t  reserved[7];
+} lh264_slice_t;
+
+/* A picture in HBM: three planes with the reference's padded layout
+ * (pic_queue.cpp:62-112): stride = align32(W + 64) luma, half for chroma;
+ * plane pointers address pixel (0,0), padding lies at negative offsets. */
+typedef struct lh264_pic {
+  uint8_t* y_dev;
+  uint8_t* u_dev;
+  uint8_t* v_dev;
+} lh264_pic_t;
+
+/* One frame to reconstruct (== one run of the reference's per-slice loop for every
+ * slice NAL of an access unit + ExpandReferencingPicture). */
+typedef struct lh264_frame_job {
+  const lh264_mb_t*    mbs_dev;     /* mb_w*mb_h records, raster order                    */
+  const int16_t*       coeffs_dev;  /* mb_w*mb_h*384, pScaledTCoeff layout*/
+  const lh264_slice_t* slices_dev;  /* n_slices entries                                   */
+  lh264_pic_t          dst;         /* picture being reconstructed                        */
+  lh264_pic_t          ref[LH264_MAX_REFS]; /* reference pictures (deblocked + padded)    */
+  int32_t  mb_w, mb_h;
+  int32_t  stride_y, stride_c;
+  int32_t  n_slices;
+  int32_t  flags;                   /* LH264_JOB_* */
+} lh264_frame_job_t;
+
+#define LH264_JOB_NO_EXPAND   0x1   /* skip border replication (non-reference picture)    */
+#define LH264_JOB_NO_DEBLOCK  0x2   /* debug: stop after reconstruction (pre-deblock planes) */
+
+/* ---- library / device management ----------------------------------------- */
+int         lh264_abi_version(void);
+const char* lh264_last_error(void);
+/* number of visible HIP devices (<=0: none; every compute entry point then fails loudly) */
+int         lh264_device_count(void);
+int         lh264_set_device(int device);
+
+void* lh264_dev_malloc(size_t bytes);
+int   lh264_dev_free(void* p_dev);
+int   lh264_memcpy_h2d(void* dst_dev, const void* src, size_t bytes, void* hip_stream);
+int   lh264_memcpy_d2h(void* dst, const void* src_dev, size_t bytes, void* hip_stream);
+int   lh264_dev_memset(void* dst_dev, int value, size_t bytes, void* hip_stream);
+int   lh264_stream_sync(void* hip_stream);
+
+/* bytes of one padded picture (all three planes, incl. padding) and the offsets
+ * of pixel (0,0) of each plane inside such an allocation. */
+size_t lh264_pic_bytes(int mb_w, int mb_h, int* stride_y, int* stride_c,
+                       size_t* off_y, size_t* off_u, size_t* off_v);
+
+/* ---- the hot path ---------------------------------------------------------
+ * Reconstruct a batch of independent frames: intra/inter prediction + inverse
+ * transforms (WelsTargetMbConstruction), in-loop deblocking
+ * (WelsDeblockingFilterSlice) and border expansion (ExpandReferencingPicture).
+ * jobs_dev: n_jobs descriptors resident in HBM. Frames in one call must not
+ * reference each other (a P frame and its reference go in successive calls on
+ * the same stream). Asynchronous on hip_stream (NULL = default stream).
+ * Returns 0 or a negative LH264_E_* code. */
+int lh264_recon_frames(const lh264_frame_job_t* jobs_dev, int n_jobs, int max_mb_w, int max_mb_h,
+                       void* hip_stream);
+
+/* Sequential chains: chain c reconstructs jobs_dev[chain_first[c] .. chain_first[c+1]-1]
+ * in order inside one workgroup (frames of one stream: P frames may reference
+ * earlier jobs of the same chain). chain_first_dev has n_chains+1 entries. */
+int lh264_recon_chains(const lh264_frame_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
+                       int max_mb_w, int max_mb_h, void* hip_stream);
+
+/* timing helper for bench.py: time `iters` back-to-back invocations of the
+ * dominant kernel with hipEvents on the launch stream; returns mean ms per
+ * launch (<0 on error). */
+double lh264_time_recon_chains(const lh264_frame_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
+                               int max_mb_w, int max_mb_h, int iters, void* hip_stream);
+
+#define LH264_OK            0
+#define LH264_E_NODEVICE   -1
+#define LH264_E_ARG        -2
+#define LH264_E_HIP        -3
+#define LH264_E_UNSUPPORTED -4
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LH264_H_ */

@@ -1,0 +1,301 @@
+// TEST INFRASTRUCTURE ONLY (oracle/): our own shim around the *reference* decoder.
+//
+// Links against the reference libraries built by oracle/Makefile from the sources
+// in /root/reference (nothing of the reference is copied here) and decodes one or
+// more .264 files through ISVCDecoder::DecodeFrameNoDelay exactly like the
+// reference CLI does (codec/console/dec/src/h264dec.cpp:246-364).  Two link-time
+// hooks (ld --wrap) observe the reference's hot path without modifying it:
+//
+//   WelsDec::WelsTargetSliceConstruction (decode_slice.cpp:110)  -> per-slice dump of the
+//        SDqLayer arrays (dec_frame.h:60-97) BEFORE reconstruction, i.e. what the reference
+//        hands to its reconstruct kernels, in lh264_mb_t / lh264_slice_t form;
+//   WelsDec::WelsDeblockingFilterSlice  (deblocking.cpp:872)      -> the slice's pixels after
+//        reconstruction and before the in-loop filter.
+//
+// Output: one binary file per input stream (see tests/golden/make_golden.py for the
+// reader) holding, per decoded frame: slices, macroblock records, coefficients,
+// pre-deblock planes and final (deblocked) planes.
+//
+// usage: ref_dump out_dir in1.264 [in2.264 ...]
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "codec_api.h"
+#include "codec_app_def.h"
+#include "codec_def.h"
+#include "decoder_context.h"
+#include "dec_frame.h"
+#include "slice.h"
+#include "picture.h"
+#include "wels_common_defs.h"
+
+#include "../include/lh264.h"
+
+using namespace WelsDec;
+
+namespace {
+
+struct Frame {
+  int id = -1, mb_w = 0, mb_h = 0, crop_w = 0, crop_h = 0, has_final = 0;
+  const void* dec_buf = nullptr;
+  PPicture pic = nullptr;
+  int last_first_mb = -1;
+  std::vector<lh264_slice_t> slices;
+  std::vector<lh264_mb_t> mbs;
+  std::vector<int16_t> coeffs;
+  std::vector<int32_t> ref_ids;          // union over slices, index = job ref slot
+  std::vector<uint8_t> pre[3], fin[3];
+  std::vector<uint8_t> covered;          // MB covered by some slice
+};
+
+FILE* g_out = nullptr;
+int g_nframes = 0;
+Frame g_cur;
+bool g_have_cur = false;
+std::map<const void*, int> g_buf_to_frame;   // pData[0] -> id of the last frame reconstructed there
+int g_slice_first = 0, g_slice_n = 0;
+
+void put32 (int32_t v) { fwrite (&v, 4, 1, g_out); }
+
+void flush_frame() {
+  if (!g_have_cur) return;
+  Frame& f = g_cur;
+  put32 (f.id); put32 (f.mb_w); put32 (f.mb_h); put32 ((int)f.slices.size());
+  put32 (f.crop_w); put32 (f.crop_h); put32 (f.has_final); put32 ((int)f.ref_ids.size());
+  for (int i = 0; i < LH264_MAX_REFS; i++) put32 (i < (int)f.ref_ids.size() ? f.ref_ids[i] : -1);
+  fwrite (f.slices.data(), sizeof (lh264_slice_t), f.slices.size(), g_out);
+  fwrite (f.mbs.data(), sizeof (lh264_mb_t), f.mbs.size(), g_out);
+  fwrite (f.coeffs.data(), 2, f.coeffs.size(), g_out);
+  fwrite (f.covered.data(), 1, f.covered.size(), g_out);
+  for (int p = 0; p < 3; p++) fwrite (f.pre[p].data(), 1, f.pre[p].size(), g_out);
+  for (int p = 0; p < 3; p++) fwrite (f.fin[p].data(), 1, f.fin[p].size(), g_out);
+  g_nframes++;
+  g_have_cur = false;
+}
+
+void copy_mb_pixels (PWelsDecoderContext pCtx, Frame& f, int first, int n) {
+  PPicture pic = pCtx->pDec;
+  for (int k = first; k < first + n && k < f.mb_w * f.mb_h; k++) {
+    int mx = k % f.mb_w, my = k / f.mb_w;
+    for (int p = 0; p < 3; p++) {
+      int bs = p ? 8 : 16, W = f.mb_w * bs;
+      int ls = pic->iLinesize[p ? 1 : 0];
+      for (int r = 0; r < bs; r++)
+        memcpy (&f.pre[p][(my * bs + r) * W + mx * bs], pic->pData[p] + (my * bs + r) * ls + mx * bs, bs);
+    }
+  }
+}
+
+void capture_final (Frame& f, int cw, int ch) {
+  PPicture pic = f.pic;
+  if (!pic || pic->pData[0] != f.dec_buf) {
+    // output picture is not the one we are tracking (error concealment / reordering): no final planes
+    return;
+  }
+  for (int p = 0; p < 3; p++) {
+    int bs = p ? 8 : 16, W = f.mb_w * bs, H = f.mb_h * bs;
+    int ls = pic->iLinesize[p ? 1 : 0];
+    f.fin[p].resize ((size_t)W * H);
+    for (int r = 0; r < H; r++) memcpy (&f.fin[p][(size_t)r * W], pic->pData[p] + (size_t)r * ls, W);
+  }
+  f.crop_w = cw; f.crop_h = ch; f.has_final = 1;
+}
+
+}  // namespace
+
+// ---- link-time hooks ------------------------------------------------------------------------
+namespace WelsDec {
+int32_t WelsTargetSliceConstruction (PWelsDecoderContext pCtx);
+void WelsDeblockingFilterSlice (PWelsDecoderContext pCtx, PDeblockingFilterMbFunc pDeblockMb);
+}
+extern "C" {
+int32_t __real__ZN7WelsDec27WelsTargetSliceConstructionEPNS_21TagWelsDecoderContextE (PWelsDecoderContext);
+void __real__ZN7WelsDec25WelsDeblockingFilterSliceEPNS_21TagWelsDecoderContextEPFvPNS_10TagDqLayerEPNS_19tagDeblockingFilterEiE (
+  PWelsDecoderContext, PDeblockingFilterMbFunc);
+
+int32_t __wrap__ZN7WelsDec27WelsTargetSliceConstructionEPNS_21TagWelsDecoderContextE (PWelsDecoderContext pCtx) {
+  PDqLayer L = pCtx->pCurDqLayer;
+  PSlice pSlice = &L->sLayerInfo.sSliceInLayer;
+  PSliceHeader sh = &pSlice->sSliceHeaderExt.sSliceHeader;
+  const int first = sh->iFirstMbInSlice, n = pSlice->iTotalMbInCurSlice;
+  const int mbw = L->iMbWidth, mbh = L->iMbHeight;
+  const void* buf = pCtx->pDec ? pCtx->pDec->pData[0] : nullptr;
+
+  bool new_frame = !g_have_cur || g_cur.dec_buf != buf || first <= g_cur.last_first_mb
+                   || g_cur.mb_w != mbw || g_cur.mb_h != mbh;
+  if (new_frame) {
+    flush_frame();
+    g_cur = Frame();
+    g_cur.id = g_nframes; g_cur.mb_w = mbw; g_cur.mb_h = mbh; g_cur.dec_buf = buf; g_cur.pic = pCtx->pDec;
+    g_cur.mbs.assign ((size_t)mbw * mbh, lh264_mb_t());
+    memset (g_cur.mbs.data(), 0, g_cur.mbs.size() * sizeof (lh264_mb_t));
+    g_cur.coeffs.assign ((size_t)mbw * mbh * 384, 0);
+    g_cur.covered.assign ((size_t)mbw * mbh, 0);
+    for (int p = 0; p < 3; p++) g_cur.pre[p].assign ((size_t)mbw * mbh * (p ? 64 : 256), 0);
+    g_have_cur = true;
+    g_buf_to_frame[buf] = g_cur.id;
+  }
+  Frame& f = g_cur;
+  f.last_first_mb = first;
+
+  lh264_slice_t s;
+  memset (&s, 0, sizeof (s));
+  s.first_mb = first; s.n_mbs = n;
+  s.slice_type = (uint8_t)pSlice->eSliceType;
+  s.deblock_idc = (uint8_t)sh->uiDisableDeblockingFilterIdc;
+  s.alpha_c0_offset = (int8_t)sh->iSliceAlphaC0Offset;
+  s.beta_offset = (int8_t)sh->iSliceBetaOffset;
+  s.weighted_pred = L->bUseWeightPredictionFlag ? 1 : 0;
+  s.n_refs = (uint8_t)sh->uiRefCount[0];
+  s.luma_dc_weight = pCtx->bUseScalingList ? (uint8_t)(pCtx->pDequant_coeff4x4[0][0][0] / 10) : 16; // [list 0 = Intra-Y][qp 0][pos 0] = weight * 10
+  if (L->pPredWeightTable) {
+    s.luma_log2_denom = (uint8_t)L->pPredWeightTable->uiLumaLog2WeightDenom;
+    s.chroma_log2_denom = (uint8_t)L->pPredWeightTable->uiChromaLog2WeightDenom;
+    for (int i = 0; i < LH264_MAX_REFS; i++) {
+      s.luma_weight[i] = (int16_t)L->pPredWeightTable->sPredList[0].iLumaWeight[i];
+      s.luma_offset[i] = (int16_t)L->pPredWeightTable->sPredList[0].iLumaOffset[i];
+      for (int c = 0; c < 2; c++) {
+        s.chroma_weight[i][c] = (int16_t)L->pPredWeightTable->sPredList[0].iChromaWeight[i][c];
+        s.chroma_offset[i][c] = (int16_t)L->pPredWeightTable->sPredList[0].iChromaOffset[i][c];
+      }
+    }
+  }
+  for (int i = 0; i < LH264_MAX_REFS; i++) {
+    s.ref_slot[i] = -1;
+    if (pSlice->eSliceType == P_SLICE && i < (int)sh->uiRefCount[0]) {
+      PPicture r = pCtx->sRefPic.pRefList[LIST_0][i];
+      if (!r) r = pCtx->sRefPic.pRefList[LIST_0][0];   // rec_mb.cpp:238-242 fallback
+      if (!r) continue;
+      int fid = -1;
+      std::map<const void*, int>::iterator it = g_buf_to_frame.find (r->pData[0]);
+      if (it != g_buf_to_frame.end()) fid = it->second;
+      int slot = -1;
+      for (size_t k = 0; k < f.ref_ids.size(); k++) if (f.ref_ids[k] == fid) slot = (int)k;
+      if (slot < 0 && f.ref_ids.size() < LH264_MAX_REFS) { f.ref_ids.push_back (fid); slot = (int)f.ref_ids.size() - 1; }
+      s.ref_slot[i] = (int8_t)slot;
+    }
+  }
+  const int sid = (int)f.slices.size();
+  f.slices.push_back (s);
+
+  for (int k = first; k < first + n && k < mbw * mbh; k++) {
+    lh264_mb_t& m = f.mbs[k];
+    memset (&m, 0, sizeof (m));
+    m.mb_type = (uint16_t)L->pMbType[k];
+    m.cbp = (uint8_t)L->pCbp[k];
+    m.qp_y = (uint8_t)L->pLumaQp[k];
+    m.qp_c[0] = (uint8_t)L->pChromaQp[k][0];
+    m.qp_c[1] = (uint8_t)L->pChromaQp[k][1];
+    m.flags = L->pTransformSize8x8Flag[k] ? LH264_MBF_T8x8 : 0;
+    m.intra_avail = L->pIntraNxNAvailFlag[k];
+    for (int i = 0; i < 16; i++) m.intra_mode[i] = L->pIntra4x4FinalMode[k][i];
+    if (m.mb_type == MB_TYPE_INTRA16x16) m.intra_mode[0] = L->pIntraPredMode[k][7];
+    m.chroma_mode = L->pChromaPredMode[k];
+    m.slice_id = (uint16_t)sid;
+    for (int i = 0; i < 4; i++) {
+      m.sub_type[i] = (uint8_t)L->pSubMbType[k][i];
+      m.ref_idx[i] = L->pRefIndex[0][k][((i >> 1) << 3) + ((i & 1) << 1)];
+    }
+    for (int i = 0; i < 24; i++) m.nzc[i] = (uint8_t)L->pNzc[k][i];
+    for (int i = 0; i < 16; i++) { m.mv[i][0] = L->pMv[0][k][i][0]; m.mv[i][1] = L->pMv[0][k][i][1]; }
+    memcpy (&f.coeffs[(size_t)k * 384], L->pScaledTCoeff[k], 768);
+    f.covered[k] = 1;
+    if (m.mb_type == MB_TYPE_INTRA_PCM) {
+      // the reference writes I_PCM samples into the frame while parsing (decode_slice.cpp:3213-3263);
+      // carry them in the (otherwise unused) coefficient slot
+      PPicture pic = pCtx->pDec;
+      int mx = k % mbw, my = k / mbw;
+      int16_t* c = &f.coeffs[(size_t)k * 384];
+      for (int r = 0; r < 16; r++) for (int x = 0; x < 16; x++)
+          c[r * 16 + x] = pic->pData[0][(my * 16 + r) * pic->iLinesize[0] + mx * 16 + x];
+      for (int p = 1; p < 3; p++) for (int r = 0; r < 8; r++) for (int x = 0; x < 8; x++)
+            c[256 + (p - 1) * 64 + r * 8 + x] = pic->pData[p][(my * 8 + r) * pic->iLinesize[1] + mx * 8 + x];
+      m.flags |= LH264_MBF_PCM_IN_COEFF;
+    }
+  }
+
+  g_slice_first = first; g_slice_n = n;
+  int32_t rc = __real__ZN7WelsDec27WelsTargetSliceConstructionEPNS_21TagWelsDecoderContextE (pCtx);
+  bool deblock_ran = (pSlice->eSliceType == I_SLICE || pSlice->eSliceType == P_SLICE)
+                     && sh->uiDisableDeblockingFilterIdc != 1 && n > 0;
+  if (!deblock_ran) copy_mb_pixels (pCtx, f, first, n);
+  return rc;
+}
+
+void __wrap__ZN7WelsDec25WelsDeblockingFilterSliceEPNS_21TagWelsDecoderContextEPFvPNS_10TagDqLayerEPNS_19tagDeblockingFilterEiE (
+  PWelsDecoderContext pCtx, PDeblockingFilterMbFunc fn) {
+  if (g_have_cur) copy_mb_pixels (pCtx, g_cur, g_slice_first, g_slice_n);
+  __real__ZN7WelsDec25WelsDeblockingFilterSliceEPNS_21TagWelsDecoderContextEPFvPNS_10TagDqLayerEPNS_19tagDeblockingFilterEiE (pCtx, fn);
+}
+}  // extern "C"
+
+static int decode_one (const char* in, const char* outdir) {
+  FILE* fi = fopen (in, "rb");
+  if (!fi) { fprintf (stderr, "cannot open %s\n", in); return 1; }
+  fseek (fi, 0, SEEK_END); long sz = ftell (fi); fseek (fi, 0, SEEK_SET);
+  std::vector<uint8_t> buf (sz + 4);
+  if (fread (buf.data(), 1, sz, fi) != (size_t)sz) { fclose (fi); return 1; }
+  fclose (fi);
+  static const uint8_t sc[4] = {0, 0, 0, 1};
+  memcpy (&buf[sz], sc, 4);   // h264dec.cpp:227,238 appends a start code
+
+  std::string base = in;
+  size_t sl = base.find_last_of ('/');
+  if (sl != std::string::npos) base = base.substr (sl + 1);
+  std::string outp = std::string (outdir) + "/" + base + ".dmp";
+  g_out = fopen (outp.c_str(), "wb");
+  if (!g_out) { fprintf (stderr, "cannot write %s\n", outp.c_str()); return 1; }
+  fwrite ("LH264DMP", 1, 8, g_out);
+  put32 (2); put32 (0);
+  g_nframes = 0; g_have_cur = false; g_buf_to_frame.clear();
+
+  ISVCDecoder* dec = nullptr;
+  if (WelsCreateDecoder (&dec) || !dec) { fprintf (stderr, "WelsCreateDecoder failed\n"); return 1; }
+  SDecodingParam p;
+  memset (&p, 0, sizeof (p));
+  p.eOutputColorFormat = videoFormatI420;
+  p.uiTargetDqLayer = (uint8_t) - 1;
+  p.eEcActiveIdc = ERROR_CON_SLICE_COPY;
+  p.sVideoProperty.eVideoBsType = VIDEO_BITSTREAM_DEFAULT;
+  if (dec->Initialize (&p)) { fprintf (stderr, "Initialize failed\n"); return 1; }
+
+  long pos = 0;
+  int nout = 0;
+  while (pos < sz) {
+    // next start-code-delimited chunk, as h264dec.cpp:246-272 does
+    long i;
+    for (i = 0; i < sz - pos; i++) {
+      if ((buf[pos + i] == 0 && buf[pos + i + 1] == 0 && buf[pos + i + 2] == 0 && buf[pos + i + 3] == 1 && i > 0) ||
+          (buf[pos + i] == 0 && buf[pos + i + 1] == 0 && buf[pos + i + 2] == 1 && i > 0)) break;
+    }
+    long slice = i;
+    if (slice < 4) { pos += slice; continue; }
+    uint8_t* dst[3] = {0, 0, 0};
+    SBufferInfo info;
+    memset (&info, 0, sizeof (info));
+    dec->DecodeFrameNoDelay (buf.data() + pos, (int)slice, dst, &info);
+    if (info.iBufferStatus == 1) {
+      if (g_have_cur) capture_final (g_cur, info.UsrData.sSystemBuffer.iWidth, info.UsrData.sSystemBuffer.iHeight);
+      nout++;
+    }
+    pos += slice;
+  }
+  flush_frame();
+  fseek (g_out, 12, SEEK_SET); put32 (g_nframes);
+  fclose (g_out); g_out = nullptr;
+  dec->Uninitialize();
+  WelsDestroyDecoder (dec);
+  fprintf (stderr, "%s: %d frames dumped, %d output -> %s\n", in, g_nframes, nout, outp.c_str());
+  return 0;
+}
+
+int main (int argc, char** argv) {
+  if (argc < 3) { fprintf (stderr, "usage: ref_dump out_dir in.264 [...]\n"); return 2; }
+  int rc = 0;
+  for (int i = 2; i < argc; i++) rc |= decode_one (argv[i], argv[1]);
+  return rc;
+}

@@ -1,0 +1,63 @@
+"""Reader for the binary dumps written by oracle/ref_dump.cpp (test infrastructure).
+
+The dump holds what the *reference* decoder handed to its reconstruct path
+(lh264_mb_t / lh264_slice_t records + coefficients) and what came out
+(pre-deblock and final planes); tests/golden/make_golden.py turns dumps into
+the small committed fixtures.
+"""
+import numpy as np
+
+MB_DTYPE = np.dtype([
+    ("mb_type", "<u2"), ("cbp", "u1"), ("qp_y", "u1"), ("qp_c", "u1", (2,)), ("flags", "u1"),
+    ("intra_avail", "u1"), ("intra_mode", "i1", (16,)), ("chroma_mode", "i1"), ("reserved0", "u1"),
+    ("slice_id", "<u2"), ("sub_type", "u1", (4,)), ("ref_idx", "i1", (4,)), ("nzc", "u1", (24,)),
+    ("mv", "<i2", (16, 2)), ("reserved1", "u1", (4,)),
+])
+assert MB_DTYPE.itemsize == 128
+
+SLICE_DTYPE = np.dtype([
+    ("first_mb", "<i4"), ("n_mbs", "<i4"), ("slice_type", "u1"), ("deblock_idc", "u1"),
+    ("alpha_c0_offset", "i1"), ("beta_offset", "i1"), ("weighted_pred", "u1"), ("luma_log2_denom", "u1"),
+    ("chroma_log2_denom", "u1"), ("n_refs", "u1"),
+    ("luma_weight", "<i2", (16,)), ("luma_offset", "<i2", (16,)),
+    ("chroma_weight", "<i2", (16, 2)), ("chroma_offset", "<i2", (16, 2)),
+    ("ref_slot", "i1", (16,)), ("luma_dc_weight", "u1"), ("reserved", "u1", (7,)),
+])
+assert SLICE_DTYPE.itemsize == 232, SLICE_DTYPE.itemsize
+
+
+class Frame:
+    __slots__ = ("id", "mb_w", "mb_h", "crop_w", "crop_h", "has_final", "ref_ids", "slices", "mbs",
+                 "coeffs", "covered", "pre", "fin")
+
+
+def read_dump(path, max_frames=None):
+    data = np.fromfile(path, dtype=np.uint8)
+    assert bytes(data[:8]) == b"LH264DMP", "bad magic"
+    ver, nfr = np.frombuffer(data[8:16].tobytes(), "<i4")
+    assert ver == 2
+    pos = 16
+    frames = []
+    for _ in range(nfr if max_frames is None else min(nfr, max_frames)):
+        hdr = np.frombuffer(data[pos:pos + 32 + 64].tobytes(), "<i4")
+        pos += 96
+        f = Frame()
+        f.id, f.mb_w, f.mb_h, nsl, f.crop_w, f.crop_h, f.has_final, nref = [int(x) for x in hdr[:8]]
+        f.ref_ids = [int(x) for x in hdr[8:8 + nref]]
+        n = f.mb_w * f.mb_h
+        f.slices = np.frombuffer(data[pos:pos + nsl * 232].tobytes(), SLICE_DTYPE).copy(); pos += nsl * 232
+        f.mbs = np.frombuffer(data[pos:pos + n * 128].tobytes(), MB_DTYPE).copy(); pos += n * 128
+        f.coeffs = np.frombuffer(data[pos:pos + n * 768].tobytes(), "<i2").reshape(n, 384).copy(); pos += n * 768
+        f.covered = data[pos:pos + n].copy(); pos += n
+        f.pre, f.fin = [], []
+        for p in range(3):
+            bs = 8 if p else 16
+            sz = n * bs * bs
+            f.pre.append(data[pos:pos + sz].reshape(f.mb_h * bs, f.mb_w * bs).copy()); pos += sz
+        if f.has_final:
+            for p in range(3):
+                bs = 8 if p else 16
+                sz = n * bs * bs
+                f.fin.append(data[pos:pos + sz].reshape(f.mb_h * bs, f.mb_w * bs).copy()); pos += sz
+        frames.append(f)
+    return frames
