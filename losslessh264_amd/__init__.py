@@ -1,0 +1,11 @@
+"""losslessh264_amd - MI355X-native decode-reconstruct hot path of the lossless H.264 recompressor.
+
+The product is the C-ABI library `liblh264.so` (include/lh264.h, hand-written gfx950 HIP kernels);
+this package is the thin Python host side used by tests and bench.py: it only moves bytes into HBM
+(torch tensors as plain device buffers) and calls the C ABI through ctypes.  There is no CPU
+fallback: without the built library or without a GPU every compute call raises.
+"""
+from ._lib import lib, LibraryMissing, MB_DTYPE, SLICE_DTYPE, JOB_DTYPE, pic_geometry  # noqa: F401
+from .recon import ReconSession  # noqa: F401
+
+__all__ = ["lib", "LibraryMissing", "ReconSession", "MB_DTYPE", "SLICE_DTYPE", "JOB_DTYPE", "pic_geometry"]

@@ -1,0 +1,85 @@
+"""ctypes binding of liblh264.so (the C ABI of include/lh264.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "liblh264.so")
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+# record layouts == include/lh264.h
+MB_DTYPE = np.dtype([
+    ("mb_type", "<u2"), ("cbp", "u1"), ("qp_y", "u1"), ("qp_c", "u1", (2,)), ("flags", "u1"),
+    ("intra_avail", "u1"), ("intra_mode", "i1", (16,)), ("chroma_mode", "i1"), ("reserved0", "u1"),
+    ("slice_id", "<u2"), ("sub_type", "u1", (4,)), ("ref_idx", "i1", (4,)), ("nzc", "u1", (24,)),
+    ("mv", "<i2", (16, 2)), ("reserved1", "u1", (4,)),
+])
+SLICE_DTYPE = np.dtype([
+    ("first_mb", "<i4"), ("n_mbs", "<i4"), ("slice_type", "u1"), ("deblock_idc", "u1"),
+    ("alpha_c0_offset", "i1"), ("beta_offset", "i1"), ("weighted_pred", "u1"), ("luma_log2_denom", "u1"),
+    ("chroma_log2_denom", "u1"), ("n_refs", "u1"),
+    ("luma_weight", "<i2", (16,)), ("luma_offset", "<i2", (16,)),
+    ("chroma_weight", "<i2", (16, 2)), ("chroma_offset", "<i2", (16, 2)),
+    ("ref_slot", "i1", (16,)), ("luma_dc_weight", "u1"), ("reserved", "u1", (7,)),
+])
+JOB_DTYPE = np.dtype([
+    ("mbs", "<u8"), ("coeffs", "<u8"), ("slices", "<u8"),
+    ("dst", "<u8", (3,)), ("ref", "<u8", (16, 3)),
+    ("mb_w", "<i4"), ("mb_h", "<i4"), ("stride_y", "<i4"), ("stride_c", "<i4"), ("n_slices", "<i4"), ("flags", "<i4"),
+])
+assert MB_DTYPE.itemsize == 128 and SLICE_DTYPE.itemsize == 232 and JOB_DTYPE.itemsize == 456
+
+JOB_NO_EXPAND, JOB_NO_DEBLOCK = 1, 2
+PAD_Y, PAD_C = 32, 16
+
+_lib = None
+
+_SIGS = {
+    "lh264_abi_version": (C.c_int, []),
+    "lh264_last_error": (C.c_char_p, []),
+    "lh264_device_count": (C.c_int, []),
+    "lh264_set_device": (C.c_int, [C.c_int]),
+    "lh264_dev_malloc": (C.c_void_p, [C.c_size_t]),
+    "lh264_dev_free": (C.c_int, [C.c_void_p]),
+    "lh264_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lh264_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lh264_dev_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "lh264_stream_sync": (C.c_int, [C.c_void_p]),
+    "lh264_pic_bytes": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t),
+                                    C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "lh264_recon_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "lh264_recon_chains": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "lh264_time_recon_chains": (C.c_double, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+EXPORTS = sorted(_SIGS)
+
+
+def lib():
+    """the loaded C-ABI library; raises LibraryMissing when it has not been built"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise LibraryMissing("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("liblh264: error %d: %s" % (rc, lib().lh264_last_error().decode()))
+
+
+def pic_geometry(mb_w, mb_h):
+    sy, sc = C.c_int(), C.c_int()
+    oy, ou, ov = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    total = lib().lh264_pic_bytes(mb_w, mb_h, C.byref(sy), C.byref(sc), C.byref(oy), C.byref(ou), C.byref(ov))
+    return sy.value, sc.value, oy.value, ou.value, ov.value, total

@@ -1,0 +1,147 @@
+// lh264_capi.hip - the C ABI declared in include/lh264.h (host side of the hot path).
+// No CPU fallback: every compute entry point fails with LH264_E_NODEVICE when no HIP device is
+// visible.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include "../../include/lh264.h"
+
+namespace lh264 {
+__global__ void recon_chain_kernel (const lh264_frame_job_t* jobs, const int32_t* chain_first, int n_chains, int line_bytes);
+size_t wave_lds_bytes();
+}
+
+static thread_local std::string g_err;
+static int fail (int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[256];
+  if (e != hipSuccess) snprintf (buf, sizeof (buf), "%s: %s", what, hipGetErrorString (e));
+  else snprintf (buf, sizeof (buf), "%s", what);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail (LH264_E_HIP, #call, e_); } while (0)
+
+extern "C" {
+
+int lh264_abi_version (void) { return LH264_ABI_VERSION; }
+const char* lh264_last_error (void) { return g_err.c_str(); }
+
+int lh264_device_count (void) {
+  int n = 0;
+  if (hipGetDeviceCount (&n) != hipSuccess) return 0;
+  return n;
+}
+int lh264_set_device (int device) {
+  if (lh264_device_count() <= 0) return fail (LH264_E_NODEVICE, "no HIP device visible");
+  HIPCHK (hipSetDevice (device));
+  return LH264_OK;
+}
+
+void* lh264_dev_malloc (size_t bytes) {
+  void* p = nullptr;
+  if (lh264_device_count() <= 0) { fail (LH264_E_NODEVICE, "no HIP device visible"); return nullptr; }
+  hipError_t e = hipMalloc (&p, bytes);
+  if (e != hipSuccess) { fail (LH264_E_HIP, "hipMalloc", e); return nullptr; }
+  return p;
+}
+int lh264_dev_free (void* p) { HIPCHK (hipFree (p)); return LH264_OK; }
+int lh264_memcpy_h2d (void* dst, const void* src, size_t bytes, void* stream) {
+  HIPCHK (hipMemcpyAsync (dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return LH264_OK;
+}
+int lh264_memcpy_d2h (void* dst, const void* src, size_t bytes, void* stream) {
+  HIPCHK (hipMemcpyAsync (dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return LH264_OK;
+}
+int lh264_dev_memset (void* dst, int value, size_t bytes, void* stream) {
+  HIPCHK (hipMemsetAsync (dst, value, bytes, (hipStream_t)stream));
+  return LH264_OK;
+}
+int lh264_stream_sync (void* stream) { HIPCHK (hipStreamSynchronize ((hipStream_t)stream)); return LH264_OK; }
+
+// the reference's picture layout (pic_queue.cpp:62-112): 32 / 16 samples of padding, luma stride aligned to 32
+size_t lh264_pic_bytes (int mb_w, int mb_h, int* stride_y, int* stride_c, size_t* off_y, size_t* off_u, size_t* off_v) {
+  const int w = mb_w * 16, h = mb_h * 16;
+  const int sy = (w + 2 * LH264_PAD_LUMA + 31) & ~31, sc = sy >> 1;
+  const size_t hy = (size_t)h + 2 * LH264_PAD_LUMA, hc = (size_t) (h >> 1) + 2 * LH264_PAD_CHROMA;
+  if (stride_y) *stride_y = sy;
+  if (stride_c) *stride_c = sc;
+  if (off_y) *off_y = (size_t)LH264_PAD_LUMA * sy + LH264_PAD_LUMA;
+  if (off_u) *off_u = (size_t)sy * hy + (size_t)LH264_PAD_CHROMA * sc + LH264_PAD_CHROMA;
+  if (off_v) *off_v = (size_t)sy * hy + (size_t)sc * hc + (size_t)LH264_PAD_CHROMA * sc + LH264_PAD_CHROMA;
+  return (size_t)sy * hy + 2 * (size_t)sc * hc + 64;   // + slack for dword reads at the very end
+}
+
+// launch geometry: one wave per macroblock row, at most 16 waves; a wave64 pool larger than the number of
+// rows that can be in flight (min(rows, ceil(w/2))) is wasted
+static int pick_waves (int max_mb_w, int max_mb_h) {
+  int inflight = (max_mb_w + 1) / 2;
+  if (inflight > max_mb_h) inflight = max_mb_h;
+  int nw = 1;
+  while (nw < inflight && nw < 16) nw <<= 1;
+  return nw;
+}
+
+static int launch_chains (const lh264_frame_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
+                          int max_mb_w, int max_mb_h, hipStream_t st) {
+  if (lh264_device_count() <= 0) return fail (LH264_E_NODEVICE, "no HIP device visible");
+  if (!jobs_dev || !chain_first_dev || n_chains < 0 || max_mb_w <= 0 || max_mb_h <= 0) return fail (LH264_E_ARG, "bad argument");
+  if (n_chains == 0) return LH264_OK;
+  const int nw = pick_waves (max_mb_w, max_mb_h);
+  const int line_bytes = (max_mb_w * 16 + 48) + 2 * (max_mb_w * 8 + 24);
+  const size_t lds = 64 + lh264::wave_lds_bytes() * nw + (size_t) (nw + 1) * line_bytes;
+  if (lds > 160 * 1024) return fail (LH264_E_UNSUPPORTED, "picture too wide for the LDS line buffers");
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK (hipFuncSetAttribute ((const void*)lh264::recon_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL (lh264::recon_chain_kernel, dim3 (n_chains), dim3 (nw * 64), lds, st, jobs_dev, chain_first_dev, n_chains, line_bytes);
+  HIPCHK (hipGetLastError());
+  return LH264_OK;
+}
+
+int lh264_recon_chains (const lh264_frame_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
+                        int max_mb_w, int max_mb_h, void* stream) {
+  return launch_chains (jobs_dev, chain_first_dev, n_chains, max_mb_w, max_mb_h, (hipStream_t)stream);
+}
+
+int lh264_recon_frames (const lh264_frame_job_t* jobs_dev, int n_jobs, int max_mb_w, int max_mb_h, void* stream) {
+  if (lh264_device_count() <= 0) return fail (LH264_E_NODEVICE, "no HIP device visible");
+  if (n_jobs <= 0) return n_jobs == 0 ? LH264_OK : fail (LH264_E_ARG, "bad argument");
+  // independent frames = chains of length one; the index table lives in a small cached device buffer
+  static int32_t* idx_dev = nullptr;
+  static int idx_cap = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_jobs + 1 > idx_cap) {
+    if (idx_dev) hipFree (idx_dev);
+    idx_cap = n_jobs + 1 + 1024;
+    HIPCHK (hipMalloc (&idx_dev, sizeof (int32_t) * idx_cap));
+    int32_t* h = new int32_t[idx_cap];
+    for (int i = 0; i < idx_cap; i++) h[i] = i;
+    hipError_t e = hipMemcpy (idx_dev, h, sizeof (int32_t) * idx_cap, hipMemcpyHostToDevice);
+    delete[] h;
+    if (e != hipSuccess) return fail (LH264_E_HIP, "hipMemcpy", e);
+  }
+  return launch_chains (jobs_dev, idx_dev, n_jobs, max_mb_w, max_mb_h, st);
+}
+
+double lh264_time_recon_chains (const lh264_frame_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
+                                int max_mb_w, int max_mb_h, int iters, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t a, b;
+  if (hipEventCreate (&a) != hipSuccess || hipEventCreate (&b) != hipSuccess) { fail (LH264_E_HIP, "hipEventCreate"); return -1.0; }
+  if (launch_chains (jobs_dev, chain_first_dev, n_chains, max_mb_w, max_mb_h, st) != LH264_OK) return -1.0;   // warm-up
+  hipEventRecord (a, st);
+  for (int i = 0; i < iters; i++)
+    if (launch_chains (jobs_dev, chain_first_dev, n_chains, max_mb_w, max_mb_h, st) != LH264_OK) return -1.0;
+  hipEventRecord (b, st);
+  if (hipEventSynchronize (b) != hipSuccess) { fail (LH264_E_HIP, "hipEventSynchronize"); return -1.0; }
+  float ms = 0.f;
+  hipEventElapsedTime (&ms, a, b);
+  hipEventDestroy (a); hipEventDestroy (b);
+  return iters > 0 ? (double)ms / iters : 0.0;
+}
+
+}  // extern "C"
