@@ -21,7 +21,7 @@ class ReconSession:
     Every frame gets its own padded picture in HBM (sized for 288 GB parts; a DPB ring is a host policy).
     """
 
-    def __init__(self, streams, device=0, flags=0, replicate=1):
+    def __init__(self, streams, device=0, flags=0, replicate=1, share_records=True):
         torch = _torch()
         self.torch = torch
         self.lib = L.lib()
@@ -51,6 +51,12 @@ class ReconSession:
         self.d_mbs = torch.from_numpy(np.concatenate(mbs)).to(self.dev)
         self.d_coeffs = torch.from_numpy(np.concatenate(coeffs)).to(self.dev)
         self.d_slices = torch.from_numpy(np.concatenate(slices)).to(self.dev)
+        n_sl_distinct = sl_off
+        if not share_records and replicate > 1:
+            # physically independent streams: every replica owns its records in HBM
+            self.d_mbs = self.d_mbs.repeat(replicate)
+            self.d_coeffs = self.d_coeffs.repeat(replicate)
+            self.d_slices = self.d_slices.repeat(replicate)
         # ---- pictures: one per frame per chain
         self.pic_off = []        # [chain][frame] -> byte offset into d_pics
         total = 0
@@ -76,7 +82,10 @@ class ReconSession:
             chain_first[c] = j
             info = self.frame_info[c % len(streams)]
             id2idx = {fi[5]: i for i, fi in enumerate(info)}
+            blk = 0 if share_records else c // len(streams)
             for i, (mo, so, ns, w, h, fid, refs) in enumerate(info):
+                mo += blk * self.n_mbs_distinct
+                so += blk * n_sl_distinct
                 sy, sc, oy, ou, ov, _ = self.geo[(w, h)]
                 jb = jobs[j]
                 jb["mbs"] = base_m + mo * 128

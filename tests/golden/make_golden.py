@@ -38,6 +38,12 @@ STREAMS = [
 ]
 
 
+# full-length record sets for bench.py (config #2 seed stream); CRCs only, no planes
+BENCH_STREAMS = [
+    ("res/BA_MW_D.264", 100),
+]
+
+
 def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
 
@@ -47,9 +53,10 @@ def main():
     if not os.path.exists(dump_bin):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     tmp = tempfile.mkdtemp(prefix="lh264_golden_")
-    subprocess.check_call([dump_bin, tmp] + [os.path.join(REF, s) for s, _ in STREAMS],
+    subprocess.check_call([dump_bin, tmp] + sorted(set(os.path.join(REF, s) for s, _ in STREAMS + BENCH_STREAMS)),
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    for stream, nmax in STREAMS:
+    for stream, nmax in STREAMS + BENCH_STREAMS:
+        bench = (stream, nmax) in BENCH_STREAMS
         base = os.path.basename(stream)
         frames = read_dump(os.path.join(tmp, base + ".dmp"), nmax)
         out = {"n_frames": np.int32(len(frames))}
@@ -65,14 +72,15 @@ def main():
             out["cval_%d" % i] = f.coeffs.reshape(-1)[nz]
             out["covered_%d" % i] = f.covered
             crcs.append([crc(p) for p in f.pre] + ([crc(p) for p in f.fin] if f.has_final else [0, 0, 0]))
-            if i in (0, len(frames) - 1):       # full planes for the first and last frame (debugging aid)
+            if not bench and i in (0, len(frames) - 1):       # full planes for the first and last frame (debugging aid)
                 for p in range(3):
                     out["pre_%d_%d" % (i, p)] = f.pre[p]
                     if f.has_final:
                         out["fin_%d_%d" % (i, p)] = f.fin[p]
         out["hdr"] = np.array(hdr, dtype=np.int32)
         out["crc"] = np.array(crcs, dtype=np.uint32)
-        path = os.path.join(HERE, base + ".npz")
+        out["stream_bytes"] = np.int64(os.path.getsize(os.path.join(REF, stream)))
+        path = os.path.join(HERE, ("bench_" if bench else "") + base + ".npz")
         np.savez_compressed(path, **out)
         print("%s: %d frames -> %s (%d KB)" % (stream, len(frames), path, os.path.getsize(path) // 1024))
 

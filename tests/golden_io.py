@@ -15,12 +15,14 @@ class GFrame:
 
 
 def list_fixtures():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                  if not os.path.basename(p).startswith("bench_"))
 
 
 def load(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     frames = []
+    load.stream_bytes = int(z["stream_bytes"]) if "stream_bytes" in z else 0
     for i in range(int(z["n_frames"])):
         h = z["hdr"][i]
         f = GFrame()
