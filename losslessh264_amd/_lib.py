@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "liblh264.so")
+SO_PATH = os.environ.get("LH264_SO", os.path.join(HERE, "liblh264.so"))   # LH264_SO: tuning experiments only
 
 
 class LibraryMissing(RuntimeError):
@@ -65,6 +65,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(SO_PATH):
             raise LibraryMissing("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % SO_PATH)
+        try:
+            import torch  # noqa: F401  -- load torch's bundled HIP runtime first so the process has exactly one
+        except Exception:  # pragma: no cover
+            pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in _SIGS.items():
             f = getattr(L, name)

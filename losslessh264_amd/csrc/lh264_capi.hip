@@ -10,6 +10,10 @@
 namespace lh264 {
 __global__ void recon_chain_kernel (const lh264_frame_job_t* jobs, const int32_t* chain_first, int n_chains, int line_bytes);
 size_t wave_lds_bytes();
+size_t wg_lds_bytes();
+#ifdef LH264_STAMP
+void read_stamps (unsigned long long* out, bool reset);
+#endif
 }
 
 static thread_local std::string g_err;
@@ -73,14 +77,19 @@ size_t lh264_pic_bytes (int mb_w, int mb_h, int* stride_y, int* stride_c, size_t
   return (size_t)sy * hy + 2 * (size_t)sc * hc + 64;   // + slack for dword reads at the very end
 }
 
-// launch geometry: one wave per macroblock row, at most 16 waves; a wave64 pool larger than the number of
-// rows that can be in flight (min(rows, ceil(w/2))) is wasted
-static int pick_waves (int max_mb_w, int max_mb_h) {
+// launch geometry: one wave per macroblock row, at most 8 waves; a wave64 pool larger than the number of rows
+// that can be in flight (min(rows, ceil(w/2))) is wasted.  LDS: per-wave tiles + (NW+1) row slots holding the
+// unfiltered (32 B/MB + 96) and filtered (96 B/MB) bottom rows of a macroblock row.
+static int pick_waves (int max_mb_w, int max_mb_h, int slot_bytes, size_t* lds_out) {
   int inflight = (max_mb_w + 1) / 2;
   if (inflight > max_mb_h) inflight = max_mb_h;
   int nw = 1;
-  while (nw < inflight && nw < 16) nw <<= 1;
-  return nw;
+  while (nw < inflight && nw < 8) nw <<= 1;
+  for (;;) {
+    const size_t lds = lh264::wg_lds_bytes() + lh264::wave_lds_bytes() * nw + (size_t) (nw + 1) * slot_bytes;
+    if (lds <= 160 * 1024 || nw == 1) { *lds_out = lds; return nw; }
+    nw >>= 1;
+  }
 }
 
 static int launch_chains (const lh264_frame_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
@@ -88,16 +97,16 @@ static int launch_chains (const lh264_frame_job_t* jobs_dev, const int32_t* chai
   if (lh264_device_count() <= 0) return fail (LH264_E_NODEVICE, "no HIP device visible");
   if (!jobs_dev || !chain_first_dev || n_chains < 0 || max_mb_w <= 0 || max_mb_h <= 0) return fail (LH264_E_ARG, "bad argument");
   if (n_chains == 0) return LH264_OK;
-  const int nw = pick_waves (max_mb_w, max_mb_h);
-  const int line_bytes = (max_mb_w * 16 + 48) + 2 * (max_mb_w * 8 + 24);
-  const size_t lds = 64 + lh264::wave_lds_bytes() * nw + (size_t) (nw + 1) * line_bytes;
+  const int slot_bytes = 128 * max_mb_w + 96;
+  size_t lds = 0;
+  const int nw = pick_waves (max_mb_w, max_mb_h, slot_bytes, &lds);
   if (lds > 160 * 1024) return fail (LH264_E_UNSUPPORTED, "picture too wide for the LDS line buffers");
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK (hipFuncSetAttribute ((const void*)lh264::recon_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL (lh264::recon_chain_kernel, dim3 (n_chains), dim3 (nw * 64), lds, st, jobs_dev, chain_first_dev, n_chains, line_bytes);
+  hipLaunchKernelGGL (lh264::recon_chain_kernel, dim3 (n_chains), dim3 (nw * 64), lds, st, jobs_dev, chain_first_dev, n_chains, slot_bytes);
   HIPCHK (hipGetLastError());
   return LH264_OK;
 }
@@ -143,5 +152,10 @@ double lh264_time_recon_chains (const lh264_frame_job_t* jobs_dev, const int32_t
   hipEventDestroy (a); hipEventDestroy (b);
   return iters > 0 ? (double)ms / iters : 0.0;
 }
+
+#ifdef LH264_STAMP
+// diagnostic builds only (not declared in lh264.h)
+void lh264_debug_read_stamps (unsigned long long* out16, int reset) { lh264::read_stamps (out16, reset != 0); }
+#endif
 
 }  // extern "C"
