@@ -180,6 +180,44 @@ int lh264_recon_chains(const lh264_frame_job_t* jobs_dev, const int32_t* chain_f
 double lh264_time_recon_chains(const lh264_frame_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
                                int max_mb_w, int max_mb_h, int iters, void* hip_stream);
 
+/* ---- per-coefficient context-model index -------------------------------------------------
+ * For every coefficient symbol of a macroblock the recompressor codes (luma/chroma DC, per-block nonzero count,
+ * coefficients in zig-zag order) compute WHICH adaptive prior codes it: the flat index into the reference's
+ * tables lumaDCIntPriors / chromaDCIntPriors / nonzerosPriors[8x8] / acPriors[8x8] (macroblock_model.h:45-53),
+ * i.e. what getLumaDCIntPrior, getChromaDCIntPrior, getNonzerosPrior4x4/8x8 and getACPrior4x4/8x8
+ * (macroblock_model.cpp:466-594) return, driven like encode4x4 (decode_slice.cpp:2059-2094, 2393-2434).
+ * The adaptive update and the arithmetic coder (rows a9/a10) consume these symbols on the host side. */
+typedef struct lh264_ctx_sym {
+  uint32_t prior;     /* flat index into the table selected by `kind`                                  */
+  int16_t  value;     /* the integer that is coded with that prior                                     */
+  uint8_t  kind;      /* LH264_SYM_*                                                                   */
+  uint8_t  pad;
+} lh264_ctx_sym_t;
+enum { LH264_SYM_LUMA_DC = 0, LH264_SYM_CHROMA_DC = 1, LH264_SYM_NZ4 = 2, LH264_SYM_AC4 = 3, LH264_SYM_NZ8 = 4, LH264_SYM_AC8 = 5 };
+#define LH264_CTX_MAX_SYMS 432   /* 16 + 8 + 24 + 384 symbols per macroblock at most */
+
+/* One frame of context-index work.  `levels` = the raw (not dequantised) coefficient levels in the
+ * pScaledTCoeffQuant layout (what the reference copies into DecodedMacroblock::odata, decode_slice.cpp:69-79).
+ * nnz images: 24 bytes per macroblock = per-4x4 nonzero counts (DecodedMacroblock::countSubblockNonzeros) of the
+ * reference's FreqImage entry of that position: a skipped macroblock inherits the PAST entry
+ * (decode_slice.cpp:3104-3108).  The host decides which earlier frame is PAST (frame_num flips, resolution
+ * changes: decoded_macroblock.h:119-123, decode_slice.cpp:3032-3046) by pointing nnz_past_dev at its image. */
+typedef struct lh264_ctx_job {
+  const lh264_mb_t*    mbs_dev;       /* mb_w*mb_h records                                       */
+  const int16_t*       levels_dev;    /* mb_w*mb_h*384                                           */
+  const lh264_slice_t* slices_dev;
+  const uint8_t*       nnz_past_dev;  /* mb_w*mb_h*24 or NULL (no PAST)                          */
+  uint8_t*             nnz_cur_dev;   /* mb_w*mb_h*24, written by pass 1, read by pass 2 and later frames */
+  lh264_ctx_sym_t*     syms_dev;      /* mb_w*mb_h*LH264_CTX_MAX_SYMS, first n_syms[mb] valid, emission order */
+  uint16_t*            n_syms_dev;    /* mb_w*mb_h                                               */
+  int32_t  mb_w, mb_h;
+} lh264_ctx_job_t;
+
+/* chains as in lh264_recon_chains (frames of one stream in order: the nnz image of a frame may be the PAST of a
+ * later one).  Pass 1 (nnz images) runs one workgroup per chain, pass 2 (symbols) one wave per macroblock. */
+int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
+                            int n_jobs, int max_mbs_per_frame, void* hip_stream);
+
 #define LH264_OK            0
 #define LH264_E_NODEVICE   -1
 #define LH264_E_ARG        -2

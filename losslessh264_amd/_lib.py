@@ -87,3 +87,12 @@ def pic_geometry(mb_w, mb_h):
     oy, ou, ov = C.c_size_t(), C.c_size_t(), C.c_size_t()
     total = lib().lh264_pic_bytes(mb_w, mb_h, C.byref(sy), C.byref(sc), C.byref(oy), C.byref(ou), C.byref(ov))
     return sy.value, sc.value, oy.value, ou.value, ov.value, total
+
+# ---- context-index (row a8) ----------------------------------------------------------------------------------
+CTX_SYM_DTYPE = np.dtype([("prior", "<u4"), ("value", "<i2"), ("kind", "u1"), ("pad", "u1")])
+CTX_JOB_DTYPE = np.dtype([("mbs", "<u8"), ("levels", "<u8"), ("slices", "<u8"), ("nnz_past", "<u8"), ("nnz_cur", "<u8"),
+                          ("syms", "<u8"), ("n_syms", "<u8"), ("mb_w", "<i4"), ("mb_h", "<i4")])
+CTX_MAX_SYMS = 432
+assert CTX_SYM_DTYPE.itemsize == 8 and CTX_JOB_DTYPE.itemsize == 64
+_SIGS["lh264_ctx_index_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p])
+EXPORTS = sorted(_SIGS)

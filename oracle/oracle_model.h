@@ -5,7 +5,18 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-int orc_model_version (void);
+
+/* one context-model symbol: which prior (flat index into the reference's table) codes which integer */
+typedef struct orc_sym { uint32_t prior; int16_t value; uint8_t kind; uint8_t pad; } orc_sym_t;
+enum { ORC_SYM_LUMA_DC = 0, ORC_SYM_CHROMA_DC = 1, ORC_SYM_NZ4 = 2, ORC_SYM_AC4 = 3, ORC_SYM_NZ8 = 4, ORC_SYM_AC8 = 5 };
+#define ORC_MAX_SYMS 432   /* 16 + 8 + 24 + 384 */
+
+int  orc_model_mb_type_code (int mb_type);
+void orc_model_nnz24 (const int16_t levels[384], uint8_t nnz[24]);
+/* symbols of one macroblock in emission order; nnz_* = per-4x4 nonzero counts of the LEFT / ABOVE / PAST
+ * macroblocks as the model sees them (NULL = neighbour absent). returns the number of symbols. */
+int  orc_model_mb_symbols (const int16_t levels[384], int mb_type, int slice_type, int cbp, int t8,
+                           const uint8_t* nnz_left, const uint8_t* nnz_above, const uint8_t* nnz_past, orc_sym_t* out);
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,8 @@
 #include "slice.h"
 #include "picture.h"
 #include "wels_common_defs.h"
+#include "macroblock_model.h"
+#include "decoded_macroblock.h"
 
 #include "../include/lh264.h"
 
@@ -40,7 +42,7 @@ using namespace WelsDec;
 namespace {
 
 struct Frame {
-  int id = -1, mb_w = 0, mb_h = 0, crop_w = 0, crop_h = 0, has_final = 0;
+  int id = -1, mb_w = 0, mb_h = 0, crop_w = 0, crop_h = 0, has_final = 0, frame_num = 0;
   const void* dec_buf = nullptr;
   PPicture pic = nullptr;
   int last_first_mb = -1;
@@ -50,7 +52,31 @@ struct Frame {
   std::vector<int32_t> ref_ids;          // union over slices, index = job ref slot
   std::vector<uint8_t> pre[3], fin[3];
   std::vector<uint8_t> covered;          // MB covered by some slice
+  std::vector<int16_t> levels;           // pScaledTCoeffQuant (raw levels the context model reads)
+  std::vector<uint8_t> nei;              // per MB: 3 x (present, nnz[24]) for LEFT, ABOVE, PAST as the model saw them
+  std::vector<std::vector<uint8_t> > syms;   // per MB: packed symbols {u8 kind, i16 value, u32 prior}
 };
+
+// context-model observations collected while the reference parses a slice (before its reconstruction hook fires)
+struct MbObs { std::vector<uint8_t> syms; uint8_t nei[75]; bool have; };
+std::map<int, MbObs> g_obs;     // mb index -> observation of the frame being parsed
+int g_obs_mb = -1;
+void obs_sym (int kind, int value, long prior) {
+  if (g_obs_mb < 0) return;
+  std::vector<uint8_t>& v = g_obs[g_obs_mb].syms;
+  uint8_t b[7];
+  b[0] = (uint8_t)kind; int16_t vv = (int16_t)value; uint32_t pp = (uint32_t)prior;
+  memcpy (b + 1, &vv, 2); memcpy (b + 3, &pp, 4);
+  v.insert (v.end(), b, b + 7);
+}
+void obs_nnz (const DecodedMacroblock* d, uint8_t* out) {
+  out[0] = d ? 1 : 0;
+  for (int i = 0; i < 24; i++) out[1 + i] = 0;
+  if (!d) return;
+  for (int i = 0; i < 16; i++) out[1 + i] = (uint8_t)d->countSubblockNonzeros (0, i);
+  for (int i = 0; i < 4; i++) out[17 + i] = (uint8_t)d->countSubblockNonzeros (1, i);
+  for (int i = 4; i < 8; i++) out[17 + i] = (uint8_t)d->countSubblockNonzeros (2, i);
+}
 
 FILE* g_out = nullptr;
 int g_nframes = 0;
@@ -67,10 +93,14 @@ void flush_frame() {
   put32 (f.id); put32 (f.mb_w); put32 (f.mb_h); put32 ((int)f.slices.size());
   put32 (f.crop_w); put32 (f.crop_h); put32 (f.has_final); put32 ((int)f.ref_ids.size());
   for (int i = 0; i < LH264_MAX_REFS; i++) put32 (i < (int)f.ref_ids.size() ? f.ref_ids[i] : -1);
+  put32 (f.frame_num);
   fwrite (f.slices.data(), sizeof (lh264_slice_t), f.slices.size(), g_out);
   fwrite (f.mbs.data(), sizeof (lh264_mb_t), f.mbs.size(), g_out);
   fwrite (f.coeffs.data(), 2, f.coeffs.size(), g_out);
   fwrite (f.covered.data(), 1, f.covered.size(), g_out);
+  fwrite (f.levels.data(), 2, f.levels.size(), g_out);
+  fwrite (f.nei.data(), 1, f.nei.size(), g_out);
+  for (size_t k = 0; k < f.syms.size(); k++) { put32 ((int)f.syms[k].size()); fwrite (f.syms[k].data(), 1, f.syms[k].size(), g_out); }
   for (int p = 0; p < 3; p++) fwrite (f.pre[p].data(), 1, f.pre[p].size(), g_out);
   for (int p = 0; p < 3; p++) fwrite (f.fin[p].data(), 1, f.fin[p].size(), g_out);
   g_nframes++;
@@ -130,11 +160,14 @@ int32_t __wrap__ZN7WelsDec27WelsTargetSliceConstructionEPNS_21TagWelsDecoderCont
   if (new_frame) {
     flush_frame();
     g_cur = Frame();
-    g_cur.id = g_nframes; g_cur.mb_w = mbw; g_cur.mb_h = mbh; g_cur.dec_buf = buf; g_cur.pic = pCtx->pDec;
+    g_cur.id = g_nframes; g_cur.mb_w = mbw; g_cur.mb_h = mbh; g_cur.dec_buf = buf; g_cur.pic = pCtx->pDec; g_cur.frame_num = pCtx->iFrameNum;
     g_cur.mbs.assign ((size_t)mbw * mbh, lh264_mb_t());
     memset (g_cur.mbs.data(), 0, g_cur.mbs.size() * sizeof (lh264_mb_t));
     g_cur.coeffs.assign ((size_t)mbw * mbh * 384, 0);
     g_cur.covered.assign ((size_t)mbw * mbh, 0);
+    g_cur.levels.assign ((size_t)mbw * mbh * 384, 0);
+    g_cur.nei.assign ((size_t)mbw * mbh * 75, 0);
+    g_cur.syms.assign ((size_t)mbw * mbh, std::vector<uint8_t>());
     for (int p = 0; p < 3; p++) g_cur.pre[p].assign ((size_t)mbw * mbh * (p ? 64 : 256), 0);
     g_have_cur = true;
     g_buf_to_frame[buf] = g_cur.id;
@@ -203,6 +236,9 @@ int32_t __wrap__ZN7WelsDec27WelsTargetSliceConstructionEPNS_21TagWelsDecoderCont
     for (int i = 0; i < 24; i++) m.nzc[i] = (uint8_t)L->pNzc[k][i];
     for (int i = 0; i < 16; i++) { m.mv[i][0] = L->pMv[0][k][i][0]; m.mv[i][1] = L->pMv[0][k][i][1]; }
     memcpy (&f.coeffs[(size_t)k * 384], L->pScaledTCoeff[k], 768);
+    memcpy (&f.levels[(size_t)k * 384], L->pScaledTCoeffQuant[k], 768);
+    { std::map<int, MbObs>::iterator it = g_obs.find (k);
+      if (it != g_obs.end()) { f.syms[k] = it->second.syms; memcpy (&f.nei[(size_t)k * 75], it->second.nei, 75); g_obs.erase (it); } }
     f.covered[k] = 1;
     if (m.mb_type == MB_TYPE_INTRA_PCM) {
       // the reference writes I_PCM samples into the frame while parsing (decode_slice.cpp:3213-3263);
@@ -231,6 +267,73 @@ void __wrap__ZN7WelsDec25WelsDeblockingFilterSliceEPNS_21TagWelsDecoderContextEP
   if (g_have_cur) copy_mb_pixels (pCtx, g_cur, g_slice_first, g_slice_n);
   __real__ZN7WelsDec25WelsDeblockingFilterSliceEPNS_21TagWelsDecoderContextEPFvPNS_10TagDqLayerEPNS_19tagDeblockingFilterEiE (pCtx, fn);
 }
+
+// ---- context-model hooks (macroblock_model.cpp): record which prior every coefficient symbol used -------------
+#define MM_INIT _ZN15MacroblockModel21initCurrentMacroblockEP17DecodedMacroblockPN7WelsDec21TagWelsDecoderContextEPK9FreqImageii
+#define MM_NZ4  _ZN15MacroblockModel19getNonzerosPrior4x4Eii
+#define MM_NZ8  _ZN15MacroblockModel19getNonzerosPrior8x8Eii
+#define MM_AC4  _ZN15MacroblockModel13getACPrior4x4EiiiRKSt6vectorIiSaIiEEi
+#define MM_AC8  _ZN15MacroblockModel13getACPrior8x8EiiiRKSt6vectorIiSaIiEEi
+#define MM_LDC  _ZN15MacroblockModel17getLumaDCIntPriorEm
+#define MM_CDC  _ZN15MacroblockModel19getChromaDCIntPriorEm
+#define REAL_(x) __real_##x
+#define REAL(x) REAL_(x)
+#define WRAP_(x) __wrap_##x
+#define WRAP(x) WRAP_(x)
+void REAL(MM_INIT) (MacroblockModel*, DecodedMacroblock*, PWelsDecoderContext, const FreqImage*, int, int);
+MacroblockModel::NonzerosPrior* REAL(MM_NZ4) (MacroblockModel*, int, int);
+MacroblockModel::NonzerosPrior* REAL(MM_NZ8) (MacroblockModel*, int, int);
+MacroblockModel::ACPrior* REAL(MM_AC4) (MacroblockModel*, int, int, int, const std::vector<int>&, int);
+MacroblockModel::ACPrior* REAL(MM_AC8) (MacroblockModel*, int, int, int, const std::vector<int>&, int);
+MacroblockModel::DCPrior* REAL(MM_LDC) (MacroblockModel*, size_t);
+MacroblockModel::DCPrior* REAL(MM_CDC) (MacroblockModel*, size_t);
+
+void WRAP(MM_INIT) (MacroblockModel* self, DecodedMacroblock* mb, PWelsDecoderContext ctx, const FreqImage* f, int x, int y) {
+  REAL(MM_INIT) (self, mb, ctx, f, x, y);
+  g_obs_mb = y * (int)f->width + x;
+  MbObs& o = g_obs[g_obs_mb];
+  o.syms.clear();
+  obs_nnz (self->n[Nei::LEFT], o.nei); obs_nnz (self->n[Nei::ABOVE], o.nei + 25); obs_nnz (self->n[Nei::PAST], o.nei + 50);
+}
+MacroblockModel::NonzerosPrior* WRAP(MM_NZ4) (MacroblockModel* self, int color, int idx) {
+  MacroblockModel::NonzerosPrior* p = REAL(MM_NZ4) (self, color, idx);
+  const int16_t* ac = self->mb->getAC (color, idx);
+  int nz = 0;   // the value coded with this prior (decode_slice.cpp:2061-2064)
+  const bool emit_dc = color ? !(self->mb->uiCbpC == 1 || self->mb->uiCbpC == 2) : (self->mb->uiMbType != MB_TYPE_INTRA16x16);
+  for (int i = emit_dc ? 0 : 1; i < 16; i++) if (ac[i]) nz++;
+  obs_sym (2, nz, (long) (p - &self->nonzerosPriors.at (0, 0, 0, 0, 0, 0)));
+  return p;
+}
+MacroblockModel::NonzerosPrior* WRAP(MM_NZ8) (MacroblockModel* self, int color, int idx) {
+  MacroblockModel::NonzerosPrior* p = REAL(MM_NZ8) (self, color, idx);
+  const int16_t* ac = self->mb->getAC (color, idx);
+  int nz = 0;
+  for (int i = (self->mb->uiMbType != MB_TYPE_INTRA16x16) ? 0 : 1; i < 64; i++) if (ac[i]) nz++;
+  obs_sym (4, nz, (long) (p - &self->nonzerosPriors8x8.at (0, 0, 0, 0, 0, 0)));
+  return p;
+}
+MacroblockModel::ACPrior* WRAP(MM_AC4) (MacroblockModel* self, int idx, int coef, int color, const std::vector<int>& em, int nz) {
+  MacroblockModel::ACPrior* p = REAL(MM_AC4) (self, idx, coef, color, em, nz);
+  const int16_t* ac = self->mb->getAC (color, idx);
+  obs_sym (3, ac[coef], (long) (p - &self->acPriors.at (0, 0, 0, 0).at (0, 0, 0, 0, 0)));
+  return p;
+}
+MacroblockModel::ACPrior* WRAP(MM_AC8) (MacroblockModel* self, int idx, int coef, int color, const std::vector<int>& em, int nz) {
+  MacroblockModel::ACPrior* p = REAL(MM_AC8) (self, idx, coef, color, em, nz);
+  const int16_t* ac = self->mb->getAC (color, idx);
+  obs_sym (5, ac[coef], (long) (p - &self->acPriors8x8.at (0, 0, 0, 0).at (0, 0, 0, 0, 0)));
+  return p;
+}
+MacroblockModel::DCPrior* WRAP(MM_LDC) (MacroblockModel* self, size_t i) {
+  MacroblockModel::DCPrior* p = REAL(MM_LDC) (self, i);
+  obs_sym (0, self->mb->odata.lumaDC[i], (long) (p - &self->lumaDCIntPriors.at (0, 0, 0)));
+  return p;
+}
+MacroblockModel::DCPrior* WRAP(MM_CDC) (MacroblockModel* self, size_t i) {
+  MacroblockModel::DCPrior* p = REAL(MM_CDC) (self, i);
+  obs_sym (1, self->mb->odata.chromaDC[i], (long) (p - &self->chromaDCIntPriors.at (0, 0, 0)));
+  return p;
+}
 }  // extern "C"
 
 static int decode_one (const char* in, const char* outdir) {
@@ -250,8 +353,8 @@ static int decode_one (const char* in, const char* outdir) {
   g_out = fopen (outp.c_str(), "wb");
   if (!g_out) { fprintf (stderr, "cannot write %s\n", outp.c_str()); return 1; }
   fwrite ("LH264DMP", 1, 8, g_out);
-  put32 (2); put32 (0);
-  g_nframes = 0; g_have_cur = false; g_buf_to_frame.clear();
+  put32 (4); put32 (0);
+  g_nframes = 0; g_have_cur = false; g_buf_to_frame.clear(); g_obs.clear(); g_obs_mb = -1;
 
   ISVCDecoder* dec = nullptr;
   if (WelsCreateDecoder (&dec) || !dec) { fprintf (stderr, "WelsCreateDecoder failed\n"); return 1; }

@@ -53,8 +53,17 @@ def main():
     if not os.path.exists(dump_bin):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     tmp = tempfile.mkdtemp(prefix="lh264_golden_")
-    subprocess.check_call([dump_bin, tmp] + sorted(set(os.path.join(REF, s) for s, _ in STREAMS + BENCH_STREAMS)),
-                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # one process per stream: the reference keeps its context-model history (FreqImage) in function statics, so a
+    # second stream in the same process would inherit the first one's PAST (the reference CLI handles one stream
+    # per process).  Each process builds the reference's 8.78 GiB model: run at most 3 at a time.
+    todo = sorted(set(os.path.join(REF, s) for s, _ in STREAMS + BENCH_STREAMS))
+    running = []
+    while todo or running:
+        while todo and len(running) < 3:
+            running.append(subprocess.Popen([dump_bin, tmp, todo.pop()], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        running[0].wait()
+        assert running[0].returncode == 0
+        running.pop(0)
     for stream, nmax in STREAMS + BENCH_STREAMS:
         bench = (stream, nmax) in BENCH_STREAMS
         base = os.path.basename(stream)
@@ -63,7 +72,7 @@ def main():
         hdr, crcs = [], []
         for i, f in enumerate(frames):
             hdr.append([f.id, f.mb_w, f.mb_h, len(f.slices), f.crop_w, f.crop_h, f.has_final, len(f.ref_ids)]
-                       + (f.ref_ids + [-1] * 16)[:16])
+                       + (f.ref_ids + [-1] * 16)[:16] + [f.frame_num])
             out["mbs_%d" % i] = f.mbs.view(np.uint8).reshape(-1, 128)
             out["slices_%d" % i] = f.slices.view(np.uint8).reshape(-1, 232)
             # coefficients are sparse: store (flat index, value) pairs
@@ -71,6 +80,14 @@ def main():
             out["cidx_%d" % i] = nz.astype(np.uint32)
             out["cval_%d" % i] = f.coeffs.reshape(-1)[nz]
             out["covered_%d" % i] = f.covered
+            # context-model observations (row a8): raw levels, the neighbours' nonzero counts the reference's model saw,
+            # and every (kind, value, prior index) it coded for this frame
+            lz = np.flatnonzero(f.levels)
+            out["lidx_%d" % i] = lz.astype(np.uint32)
+            out["lval_%d" % i] = f.levels.reshape(-1)[lz]
+            out["nei_%d" % i] = f.nei
+            out["symcnt_%d" % i] = np.array([len(s) for s in f.syms], dtype=np.uint16)
+            out["syms_%d" % i] = np.concatenate(f.syms).view(np.uint8) if len(f.syms) else np.zeros(0, np.uint8)
             crcs.append([crc(p) for p in f.pre] + ([crc(p) for p in f.fin] if f.has_final else [0, 0, 0]))
             if not bench and i in (0, len(frames) - 1):       # full planes for the first and last frame (debugging aid)
                 for p in range(3):

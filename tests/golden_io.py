@@ -5,7 +5,7 @@ import zlib
 
 import numpy as np
 
-from refdump import MB_DTYPE, SLICE_DTYPE
+from refdump import MB_DTYPE, SLICE_DTYPE, SYM_DTYPE
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -34,6 +34,16 @@ def load(name):
         coeffs[z["cidx_%d" % i]] = z["cval_%d" % i]
         f.coeffs = coeffs.reshape(-1, 384)
         f.covered = z["covered_%d" % i]
+        f.frame_num = int(h[24]) if len(h) > 24 else 0
+        if ("lidx_%d" % i) in z:
+            levels = np.zeros(f.mb_w * f.mb_h * 384, dtype=np.int16)
+            levels[z["lidx_%d" % i]] = z["lval_%d" % i]
+            f.levels = levels.reshape(-1, 384)
+            f.nei = z["nei_%d" % i]
+            cnt = z["symcnt_%d" % i].astype(np.int64)
+            allsyms = z["syms_%d" % i].view(SYM_DTYPE)
+            offs = np.concatenate([[0], np.cumsum(cnt)])
+            f.syms = [allsyms[offs[k]:offs[k + 1]] for k in range(len(cnt))]
         f.crc_pre = [int(x) for x in z["crc"][i][:3]]
         f.crc_fin = [int(x) for x in z["crc"][i][3:]]
         f.pre = [z["pre_%d_%d" % (i, p)] for p in range(3)] if ("pre_%d_0" % i) in z else None

@@ -87,3 +87,50 @@ def recon_frame(mbs, coeffs, slices, dst, refs, flags=0):
 
 
 NO_EXPAND, NO_DEBLOCK = 1, 2
+
+
+# ---- context-model oracle (oracle/oracle_model.c) ---------------------------------------------------------------
+ORC_SYM_DTYPE = np.dtype([("prior", "<u4"), ("value", "<i2"), ("kind", "u1"), ("pad", "u1")])
+
+
+def model_nnz_images(frames, past_of):
+    """the FreqImage as 24 counts per macroblock: a skipped MB inherits the PAST entry (decode_slice.cpp:3104-3108)"""
+    L = lib()
+    imgs = []
+    for i, f in enumerate(frames):
+        n = f.mb_w * f.mb_h
+        img = np.zeros((n, 24), dtype=np.uint8)
+        past = imgs[past_of[i]] if past_of[i] is not None else None
+        lv = np.ascontiguousarray(f.levels, dtype=np.int16)
+        for k in range(n):
+            t = int(f.mbs["mb_type"][k])
+            if t == 0x100 or t == 0:
+                if past is not None:
+                    img[k] = past[k]
+            else:
+                L.orc_model_nnz24(lv[k].ctypes.data_as(C.c_void_p), img[k].ctypes.data_as(C.c_void_p))
+        imgs.append(img)
+    return imgs
+
+
+def model_frame_symbols(f, img, past):
+    """-> list (per MB) of ORC_SYM_DTYPE arrays, exactly what the reference's model codes for the frame"""
+    L = lib()
+    out = np.zeros(432, dtype=ORC_SYM_DTYPE)
+    res = []
+    zero = np.zeros(24, dtype=np.uint8)
+    lv = np.ascontiguousarray(f.levels, dtype=np.int16)
+    for k in range(f.mb_w * f.mb_h):
+        t = int(f.mbs["mb_type"][k])
+        if t in (0x100, 0x200, 0):
+            res.append(out[:0].copy())
+            continue
+        left = img[k - 1] if k % f.mb_w else zero
+        above = img[k - f.mb_w] if k >= f.mb_w else zero
+        pst = past[k] if past is not None else zero
+        st = int(f.slices["slice_type"][f.mbs["slice_id"][k]])
+        n = L.orc_model_mb_symbols(lv[k].ctypes.data_as(C.c_void_p), t, st, int(f.mbs["cbp"][k]), int(f.mbs["flags"][k]) & 1,
+                                   np.ascontiguousarray(left).ctypes.data_as(C.c_void_p), np.ascontiguousarray(above).ctypes.data_as(C.c_void_p),
+                                   np.ascontiguousarray(pst).ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        res.append(out[:n].copy())
+    return res

@@ -25,30 +25,42 @@ SLICE_DTYPE = np.dtype([
 ])
 assert SLICE_DTYPE.itemsize == 232, SLICE_DTYPE.itemsize
 
+# one context-model symbol as observed in the reference: kind 0 luma DC, 1 chroma DC, 2 nonzeros(4x4), 3 coefficient(4x4),
+# 4 nonzeros(8x8), 5 coefficient(8x8); value = the coded integer; prior = flat index into the reference's prior table
+SYM_DTYPE = np.dtype([("kind", "u1"), ("value", "<i2"), ("prior", "<u4")])
+assert SYM_DTYPE.itemsize == 7
+
 
 class Frame:
     __slots__ = ("id", "mb_w", "mb_h", "crop_w", "crop_h", "has_final", "ref_ids", "slices", "mbs",
-                 "coeffs", "covered", "pre", "fin")
+                 "coeffs", "covered", "pre", "fin", "levels", "nei", "syms", "frame_num")
 
 
 def read_dump(path, max_frames=None):
     data = np.fromfile(path, dtype=np.uint8)
     assert bytes(data[:8]) == b"LH264DMP", "bad magic"
     ver, nfr = np.frombuffer(data[8:16].tobytes(), "<i4")
-    assert ver == 2
+    assert ver == 4
     pos = 16
     frames = []
     for _ in range(nfr if max_frames is None else min(nfr, max_frames)):
-        hdr = np.frombuffer(data[pos:pos + 32 + 64].tobytes(), "<i4")
-        pos += 96
+        hdr = np.frombuffer(data[pos:pos + 32 + 64 + 4].tobytes(), "<i4")
+        pos += 100
         f = Frame()
         f.id, f.mb_w, f.mb_h, nsl, f.crop_w, f.crop_h, f.has_final, nref = [int(x) for x in hdr[:8]]
         f.ref_ids = [int(x) for x in hdr[8:8 + nref]]
+        f.frame_num = int(hdr[24])
         n = f.mb_w * f.mb_h
         f.slices = np.frombuffer(data[pos:pos + nsl * 232].tobytes(), SLICE_DTYPE).copy(); pos += nsl * 232
         f.mbs = np.frombuffer(data[pos:pos + n * 128].tobytes(), MB_DTYPE).copy(); pos += n * 128
         f.coeffs = np.frombuffer(data[pos:pos + n * 768].tobytes(), "<i2").reshape(n, 384).copy(); pos += n * 768
         f.covered = data[pos:pos + n].copy(); pos += n
+        f.levels = np.frombuffer(data[pos:pos + n * 768].tobytes(), "<i2").reshape(n, 384).copy(); pos += n * 768
+        f.nei = data[pos:pos + n * 75].reshape(n, 3, 25).copy(); pos += n * 75
+        f.syms = []
+        for _k in range(n):
+            ln = int(np.frombuffer(data[pos:pos + 4].tobytes(), "<i4")[0]); pos += 4
+            f.syms.append(np.frombuffer(data[pos:pos + ln].tobytes(), SYM_DTYPE).copy()); pos += ln
         f.pre, f.fin = [], []
         for p in range(3):
             bs = 8 if p else 16
