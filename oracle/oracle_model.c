@@ -127,3 +127,28 @@ int orc_model_mb_symbols (const int16_t levels[384], int mb_type, int slice_type
   }
   return k;
 }
+
+/* whole-frame drivers (used by bench.py's cpu_baseline so the timed CPU path has no Python in its loop) */
+void orc_model_frame_nnz (const lh264_mb_t* mbs, const int16_t* levels, int n_mbs, const uint8_t* past, uint8_t* cur) {
+  for (int k = 0; k < n_mbs; k++) {
+    const int t = mbs[k].mb_type;
+    if (t == LH264_MB_SKIP || t == 0) {
+      if (past) memcpy (cur + k * 24, past + k * 24, 24); else memset (cur + k * 24, 0, 24);
+    } else orc_model_nnz24 (levels + (size_t)k * 384, cur + k * 24);
+  }
+}
+long orc_model_frame_symbols (const lh264_mb_t* mbs, const lh264_slice_t* slices, const int16_t* levels, int mb_w, int mb_h,
+                              const uint8_t* cur, const uint8_t* past, orc_sym_t* out /* [n][432] */, uint16_t* n_out) {
+  long total = 0;
+  for (int k = 0; k < mb_w * mb_h; k++) {
+    const int t = mbs[k].mb_type;
+    int n = 0;
+    if (!(t == LH264_MB_SKIP || t == LH264_MB_IPCM || t == 0))
+      n = orc_model_mb_symbols (levels + (size_t)k * 384, t, slices[mbs[k].slice_id].slice_type, mbs[k].cbp, mbs[k].flags & LH264_MBF_T8x8,
+                                (k % mb_w) ? cur + (k - 1) * 24 : 0, k >= mb_w ? cur + (k - mb_w) * 24 : 0, past ? past + k * 24 : 0,
+                                out + (size_t)k * ORC_MAX_SYMS);
+    n_out[k] = (uint16_t)n;
+    total += n;
+  }
+  return total;
+}

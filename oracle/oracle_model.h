@@ -17,6 +17,10 @@ void orc_model_nnz24 (const int16_t levels[384], uint8_t nnz[24]);
  * macroblocks as the model sees them (NULL = neighbour absent). returns the number of symbols. */
 int  orc_model_mb_symbols (const int16_t levels[384], int mb_type, int slice_type, int cbp, int t8,
                            const uint8_t* nnz_left, const uint8_t* nnz_above, const uint8_t* nnz_past, orc_sym_t* out);
+struct lh264_mb; struct lh264_slice;
+void orc_model_frame_nnz (const struct lh264_mb* mbs, const int16_t* levels, int n_mbs, const uint8_t* past, uint8_t* cur);
+long orc_model_frame_symbols (const struct lh264_mb* mbs, const struct lh264_slice* slices, const int16_t* levels, int mb_w, int mb_h,
+                              const uint8_t* cur, const uint8_t* past, orc_sym_t* out, uint16_t* n_out);
 #ifdef __cplusplus
 }
 #endif
