@@ -218,6 +218,31 @@ typedef struct lh264_ctx_job {
 int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
                             int n_jobs, int max_mbs_per_frame, void* hip_stream);
 
+/* ---- host front end: Annex-B bitstream -> macroblock records ------------------------------
+ * Replaces, for the records the hot path needs, the reference's WelsDecodeBs / ParseNonVclNal / slice-header parse /
+ * CAVLC macroblock parse (decoder.cpp:658-860, au_parser.cpp, decode_slice.cpp:3173-3984, parse_mb_syn_cavlc.cpp).
+ * Pure host code.  Pictures come out in decode order (I and P slices only, as in the reference). */
+typedef struct lh264_parser lh264_parser_t;
+typedef struct lh264_frame_info {
+  int32_t id, mb_w, mb_h, n_slices, n_refs, frame_num;
+  int32_t crop_x, crop_y, crop_w, crop_h;      /* cropped output window in luma samples (SBufferInfo iWidth/iHeight) */
+  int32_t is_ref, idr;
+  int32_t ref_ids[LH264_MAX_REFS];             /* picture ids behind this picture's job ref slots */
+} lh264_frame_info_t;
+lh264_parser_t* lh264_parser_create (void);
+void  lh264_parser_destroy (lh264_parser_t* p);
+/* feed Annex-B bytes ending on a NAL boundary; flush != 0 completes the picture in progress. <0 on a parse error
+ * (lh264_parser_error gives the text; pictures parsed so far stay available) */
+int   lh264_parser_feed (lh264_parser_t* p, const uint8_t* data, size_t len, int flush);
+int   lh264_parser_frame_count (const lh264_parser_t* p);
+int   lh264_parser_frame_info (const lh264_parser_t* p, int idx, lh264_frame_info_t* out);
+const lh264_mb_t*    lh264_parser_frame_mbs (const lh264_parser_t* p, int idx);
+const int16_t*       lh264_parser_frame_coeffs (const lh264_parser_t* p, int idx);
+const int16_t*       lh264_parser_frame_levels (const lh264_parser_t* p, int idx);
+const lh264_slice_t* lh264_parser_frame_slices (const lh264_parser_t* p, int idx);
+const uint8_t*       lh264_parser_frame_covered (const lh264_parser_t* p, int idx);
+const char*          lh264_parser_error (const lh264_parser_t* p);
+
 #define LH264_OK            0
 #define LH264_E_NODEVICE   -1
 #define LH264_E_ARG        -2

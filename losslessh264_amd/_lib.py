@@ -56,6 +56,22 @@ _SIGS = {
     "lh264_recon_chains": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "lh264_time_recon_chains": (C.c_double, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
+FRAME_INFO_DTYPE = np.dtype([("id", "<i4"), ("mb_w", "<i4"), ("mb_h", "<i4"), ("n_slices", "<i4"), ("n_refs", "<i4"), ("frame_num", "<i4"),
+                             ("crop_x", "<i4"), ("crop_y", "<i4"), ("crop_w", "<i4"), ("crop_h", "<i4"), ("is_ref", "<i4"), ("idr", "<i4"),
+                             ("ref_ids", "<i4", (16,))])
+_SIGS.update({
+    "lh264_parser_create": (C.c_void_p, []),
+    "lh264_parser_destroy": (None, [C.c_void_p]),
+    "lh264_parser_feed": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int]),
+    "lh264_parser_frame_count": (C.c_int, [C.c_void_p]),
+    "lh264_parser_frame_info": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "lh264_parser_frame_mbs": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "lh264_parser_frame_coeffs": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "lh264_parser_frame_levels": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "lh264_parser_frame_slices": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "lh264_parser_frame_covered": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "lh264_parser_error": (C.c_char_p, [C.c_void_p]),
+})
 EXPORTS = sorted(_SIGS)
 
 

@@ -1,0 +1,909 @@
+// h264_parser.cpp - see h264_parser.h.  ITU-T H.264 clauses 7.3 (syntax), 8.2.4 (reference lists), 8.3.1.1 / 8.4.1
+// (intra mode and motion vector prediction), 9.2 (CAVLC).  Frame (progressive) pictures, I and P slices, one slice
+// group -- the subset the reference decoder itself supports.
+#include "h264_parser.h"
+#include <string.h>
+#include <algorithm>
+#include "h264_tables.h"
+#include "h264_vlc_tables.h"
+
+namespace lh264host {
+
+bool BitReader::more_rbsp_data() const {
+  if (pos >= nbits) return false;
+  // find the last set bit of the payload (the rbsp stop bit)
+  size_t last = nbits;
+  while (last > pos) {
+    size_t q = last - 1;
+    if ((p[q >> 3] >> (7 - (q & 7))) & 1) return q > pos;
+    last--;
+  }
+  return false;
+}
+
+namespace {
+
+// z-order 4x4 index <-> raster (x,y)
+inline int z2x (int z) { return (z & 1) | ((z >> 2) & 1) << 1; }
+inline int z2y (int z) { return ((z >> 1) & 1) | ((z >> 3) & 1) << 1; }
+inline int xy2z (int x, int y) { return (x & 1) | ((y & 1) << 1) | ((x >> 1) << 2) | ((y >> 1) << 3); }
+inline bool zidx_before (int x, int y, int z) { return xy2z (x, y) < z; }
+const int kChromaNzcIdx[2][4] = {{16, 17, 20, 21}, {18, 19, 22, 23}};   // reference nzc layout (common_tables.cpp:39-47)
+
+struct DpbPic {
+  int frame_id = -1, frame_num = 0, frame_num_wrap = 0, long_idx = -1;
+  bool is_long = false;
+};
+
+struct MbState {       // per-macroblock parse state of the current picture (neighbour context)
+  int16_t slice = -1;
+  uint8_t type_class = 0;   // 0 not decoded, 1 intra NxN, 2 intra other, 3 inter
+  int8_t ipm[16];           // Intra4x4PredMode per raster 4x4 (I8x8: replicated), 2 otherwise
+  int8_t ref[4];
+  int16_t mv[16][2];
+};
+
+}  // namespace
+
+struct Parser::Impl {
+  Parser* self;
+  std::map<int, Sps> sps;
+  std::map<int, Pps> pps;
+  std::vector<DpbPic> dpb;
+  int next_frame_id = 0;
+  // picture in progress
+  std::unique_ptr<FrameOut> cur;
+  std::vector<MbState> st;
+  const Sps* csps = nullptr; const Pps* cpps = nullptr;
+  SliceHeader first_sh;
+  int last_first_mb = -1;
+  int prev_ref_frame_num = 0;
+  bool cur_is_long = false; int cur_long_idx = -1; bool had_mmco5 = false;
+  std::vector<uint8_t> rbsp;
+
+  explicit Impl (Parser* s) : self (s) {}
+
+  // ---- helpers -------------------------------------------------------------------------------------------------
+  void fail (const std::string& m) { if (self->err_.empty()) self->err_ = m; }
+
+  static void unescape (const uint8_t* d, size_t n, std::vector<uint8_t>& out) {
+    out.clear(); out.reserve (n);
+    int zeros = 0;
+    for (size_t i = 0; i < n; i++) {
+      if (zeros >= 2 && d[i] == 3) { zeros = 0; continue; }
+      out.push_back (d[i]);
+      zeros = d[i] == 0 ? zeros + 1 : 0;
+    }
+  }
+
+  static void parse_scaling_list (BitReader& br, uint8_t* dst, int n, const uint8_t* fallback_raster, const uint8_t* def_zz, bool& use_default) {
+    int last = 8, next = 8;
+    use_default = false;
+    const uint8_t* zz = n == 16 ? kZigzag4x4 : kZigzag8x8;
+    for (int j = 0; j < n; j++) {
+      if (next != 0) {
+        int delta = br.se();
+        next = (last + delta + 256) % 256;
+        if (j == 0 && next == 0) { use_default = true; break; }
+      }
+      dst[zz[j]] = (uint8_t) (next == 0 ? last : next);
+      last = dst[zz[j]];
+    }
+    if (use_default) for (int j = 0; j < n; j++) dst[zz[j]] = def_zz[j];
+    (void)fallback_raster;
+  }
+  // scaling matrices of an SPS (fall-back rule A) or PPS (fall-back rule B = the SPS's lists), 7.3.2.1.1 / Table 7-2
+  static void parse_scaling_matrix (BitReader& br, uint8_t sl4[6][16], uint8_t sl8[2][64], int n_lists, const Sps* fb_sps) {
+    for (int i = 0; i < n_lists; i++) {
+      bool present = br.u1();
+      bool use_def = false;
+      if (i < 6) {
+        if (present) parse_scaling_list (br, sl4[i], 16, nullptr, kDefaultScaling4x4[i < 3 ? 0 : 1], use_def);
+        else if (i == 0 || i == 3) {
+          if (fb_sps) memcpy (sl4[i], fb_sps->sl4[i], 16);
+          else for (int j = 0; j < 16; j++) sl4[i][kZigzag4x4[j]] = kDefaultScaling4x4[i < 3 ? 0 : 1][j];
+        } else memcpy (sl4[i], sl4[i - 1], 16);
+      } else {
+        const int k = i - 6;
+        if (present) parse_scaling_list (br, sl8[k], 64, nullptr, kDefaultScaling8x8[k], use_def);
+        else if (fb_sps) memcpy (sl8[k], fb_sps->sl8[k], 64);
+        else for (int j = 0; j < 64; j++) sl8[k][kZigzag8x8[j]] = kDefaultScaling8x8[k][j];
+      }
+    }
+  }
+
+  void parse_sps (BitReader& br) {
+    Sps s;
+    s.profile_idc = br.u (8); br.u (8); s.level_idc = br.u (8);
+    int id = br.ue();
+    memset (s.sl4, 16, sizeof (s.sl4)); memset (s.sl8, 16, sizeof (s.sl8));
+    if (s.profile_idc == 100 || s.profile_idc == 110 || s.profile_idc == 122 || s.profile_idc == 244 || s.profile_idc == 44 ||
+        s.profile_idc == 83 || s.profile_idc == 86 || s.profile_idc == 118 || s.profile_idc == 128) {
+      s.chroma_format_idc = br.ue();
+      if (s.chroma_format_idc == 3) br.u1();
+      int bdl = br.ue(), bdc = br.ue();
+      br.u1();
+      if (s.chroma_format_idc != 1 || bdl || bdc) { self->n_unsupported_++; fail ("unsupported chroma format / bit depth"); return; }
+      s.scaling_matrix_present = br.u1();
+      if (s.scaling_matrix_present) parse_scaling_matrix (br, s.sl4, s.sl8, 8, nullptr);
+    }
+    s.log2_max_frame_num = br.ue() + 4;
+    s.poc_type = br.ue();
+    if (s.poc_type == 0) s.log2_max_poc_lsb = br.ue() + 4;
+    else if (s.poc_type == 1) {
+      s.delta_pic_order_always_zero = br.u1();
+      s.offset_for_non_ref_pic = br.se(); s.offset_for_top_to_bottom = br.se();
+      s.num_ref_frames_in_poc_cycle = br.ue();
+      for (int i = 0; i < s.num_ref_frames_in_poc_cycle && i < 256; i++) s.offset_for_ref_frame.push_back (br.se());
+    }
+    s.num_ref_frames = br.ue();
+    s.gaps_allowed = br.u1();
+    s.mb_w = br.ue() + 1;
+    s.mb_h = br.ue() + 1;
+    s.frame_mbs_only = br.u1();
+    if (!s.frame_mbs_only) { br.u1(); self->n_unsupported_++; fail ("interlaced coding is not supported"); return; }
+    s.direct_8x8 = br.u1();
+    if (br.u1()) { s.crop_l = br.ue(); s.crop_r = br.ue(); s.crop_t = br.ue(); s.crop_b = br.ue(); }
+    if (br.err) { fail ("truncated SPS"); return; }
+    s.valid = true;
+    sps[id] = s;
+  }
+
+  void parse_pps (BitReader& br) {
+    Pps p;
+    int id = br.ue();
+    p.sps_id = br.ue();
+    p.cabac = br.u1();
+    p.pic_order_present = br.u1();
+    p.num_slice_groups = br.ue() + 1;
+    if (p.num_slice_groups > 1) { self->n_unsupported_++; fail ("FMO (slice groups) is not supported"); return; }
+    p.num_ref_idx_l0 = br.ue() + 1; p.num_ref_idx_l1 = br.ue() + 1;
+    p.weighted_pred = br.u1(); p.weighted_bipred_idc = br.u (2);
+    p.pic_init_qp = 26 + br.se(); p.pic_init_qs = 26 + br.se();
+    p.chroma_qp_offset[0] = p.chroma_qp_offset[1] = br.se();
+    p.deblocking_control = br.u1(); p.constrained_intra_pred = br.u1(); p.redundant_pic_cnt = br.u1();
+    memset (p.sl4, 16, sizeof (p.sl4)); memset (p.sl8, 16, sizeof (p.sl8));
+    auto it = sps.find (p.sps_id);
+    if (it != sps.end()) { memcpy (p.sl4, it->second.sl4, sizeof (p.sl4)); memcpy (p.sl8, it->second.sl8, sizeof (p.sl8)); }
+    if (br.more_rbsp_data()) {
+      p.transform_8x8 = br.u1();
+      p.scaling_matrix_present = br.u1();
+      if (p.scaling_matrix_present)
+        parse_scaling_matrix (br, p.sl4, p.sl8, 6 + (p.transform_8x8 ? 2 : 0), (it != sps.end() && it->second.scaling_matrix_present) ? &it->second : nullptr);
+      p.chroma_qp_offset[1] = br.se();
+    }
+    if (br.err) { fail ("truncated PPS"); return; }
+    p.valid = true;
+    pps[id] = p;
+  }
+
+  bool parse_slice_header (BitReader& br, int nal_type, int nal_ref_idc, SliceHeader& sh) {
+    sh.idr = nal_type == 5; sh.nal_ref_idc = nal_ref_idc;
+    sh.first_mb = br.ue();
+    int st = br.ue();
+    if (st >= 5) st -= 5;
+    if (st != 0 && st != 2) { self->n_unsupported_++; fail ("only I and P slices are supported"); return false; }
+    sh.slice_type = st;
+    sh.pps_id = br.ue();
+    auto pit = pps.find (sh.pps_id);
+    if (pit == pps.end() || !pit->second.valid) { fail ("slice refers to a missing PPS"); return false; }
+    const Pps& P = pit->second;
+    auto sit = sps.find (P.sps_id);
+    if (sit == sps.end() || !sit->second.valid) { fail ("slice refers to a missing SPS"); return false; }
+    const Sps& S = sit->second;
+    sh.frame_num = br.u (S.log2_max_frame_num);
+    if (sh.idr) sh.idr_pic_id = br.ue();
+    if (S.poc_type == 0) { sh.poc_lsb = br.u (S.log2_max_poc_lsb); if (P.pic_order_present) sh.delta_poc_bottom = br.se(); }
+    else if (S.poc_type == 1 && !S.delta_pic_order_always_zero) { sh.delta_poc[0] = br.se(); if (P.pic_order_present) sh.delta_poc[1] = br.se(); }
+    if (P.redundant_pic_cnt) sh.redundant_pic_cnt = br.ue();
+    sh.num_ref_idx_l0 = P.num_ref_idx_l0;
+    if (st == 0) {
+      if (br.u1()) sh.num_ref_idx_l0 = br.ue() + 1;
+      if (br.u1()) {            // ref_pic_list_modification_flag_l0
+        for (;;) {
+          int idc = br.ue();
+          if (idc == 3 || br.err) break;
+          sh.reorder.push_back ({idc, br.ue()});
+          if (sh.reorder.size() > 64) { fail ("bad ref list modification"); return false; }
+        }
+      }
+      if (P.weighted_pred) {
+        sh.has_weights = true;
+        sh.luma_log2_denom = br.ue(); sh.chroma_log2_denom = br.ue();
+        for (int i = 0; i < sh.num_ref_idx_l0 && i < 32; i++) {
+          sh.luma_weight[i] = 1 << sh.luma_log2_denom; sh.luma_offset[i] = 0;
+          for (int c = 0; c < 2; c++) { sh.chroma_weight[i][c] = 1 << sh.chroma_log2_denom; sh.chroma_offset[i][c] = 0; }
+          if (br.u1()) { sh.luma_weight[i] = br.se(); sh.luma_offset[i] = br.se(); }
+          if (br.u1()) for (int c = 0; c < 2; c++) { sh.chroma_weight[i][c] = br.se(); sh.chroma_offset[i][c] = br.se(); }
+        }
+      }
+    }
+    if (nal_ref_idc) {
+      if (sh.idr) { sh.no_output_of_prior = br.u1(); sh.long_term_reference = br.u1(); }
+      else if ((sh.adaptive_marking = br.u1())) {
+        for (;;) {
+          int op = br.ue();
+          if (op == 0 || br.err) break;
+          SliceHeader::Mmco m = {op, 0, 0};
+          if (op == 1 || op == 3) m.a = br.ue();
+          if (op == 2) m.a = br.ue();
+          if (op == 3 || op == 6) m.b = br.ue();
+          if (op == 4) m.a = br.ue();
+          sh.mmco.push_back (m);
+          if (sh.mmco.size() > 66) { fail ("bad mmco list"); return false; }
+        }
+      }
+    }
+    if (P.cabac && st != 2) sh.cabac_init_idc = br.ue();
+    sh.slice_qp = P.pic_init_qp + br.se();
+    if (P.deblocking_control) {
+      sh.deblock_idc = br.ue();
+      if (sh.deblock_idc != 1) { sh.alpha_off = br.se() * 2; sh.beta_off = br.se() * 2; }
+    }
+    return !br.err;
+  }
+
+  // ---- reference lists (8.2.4) ----------------------------------------------------------------------------------
+  void build_ref_list (const SliceHeader& sh, const Sps& S, std::vector<int>& list /* frame ids, -1 = none */) {
+    const int max_fn = 1 << S.log2_max_frame_num;
+    std::vector<DpbPic*> sterm, lterm;
+    for (auto& d : dpb) {
+      if (d.is_long) lterm.push_back (&d);
+      else { d.frame_num_wrap = d.frame_num > sh.frame_num ? d.frame_num - max_fn : d.frame_num; sterm.push_back (&d); }
+    }
+    std::sort (sterm.begin(), sterm.end(), [] (DpbPic * a, DpbPic * b) { return a->frame_num_wrap > b->frame_num_wrap; });
+    std::sort (lterm.begin(), lterm.end(), [] (DpbPic * a, DpbPic * b) { return a->long_idx < b->long_idx; });
+    std::vector<DpbPic*> l;
+    l.insert (l.end(), sterm.begin(), sterm.end()); l.insert (l.end(), lterm.begin(), lterm.end());
+    const int n = sh.num_ref_idx_l0;
+    l.resize (std::max ((size_t)n + 1, l.size()), nullptr);
+    int pred = sh.frame_num, idx = 0;
+    for (const auto& r : sh.reorder) {
+      DpbPic* target = nullptr;
+      if (r.idc == 0 || r.idc == 1) {
+        int nowrap = r.idc == 0 ? pred - (int) (r.val + 1) : pred + (int) (r.val + 1);
+        if (r.idc == 0 && nowrap < 0) nowrap += max_fn;
+        if (r.idc == 1 && nowrap >= max_fn) nowrap -= max_fn;
+        pred = nowrap;
+        const int picnum = nowrap > sh.frame_num ? nowrap - max_fn : nowrap;
+        for (auto* d : sterm) if (d->frame_num_wrap == picnum) target = d;
+      } else if (r.idc == 2) {
+        for (auto* d : lterm) if (d->long_idx == (int)r.val) target = d;
+      }
+      if (!target || idx > n) continue;
+      l.insert (l.begin() + idx, target);
+      int w = idx + 1;
+      for (size_t k = idx + 1; k < l.size(); k++) if (l[k] != target) l[w++] = l[k];
+      l.resize (w);
+      l.resize (std::max ((size_t)n + 1, l.size()), nullptr);
+      idx++;
+    }
+    list.clear();
+    for (int i = 0; i < n; i++) list.push_back (i < (int)l.size() && l[i] ? l[i]->frame_id : -1);
+  }
+
+  void mark_reference (const SliceHeader& sh, const Sps& S) {
+    const int max_fn = 1 << S.log2_max_frame_num;
+    if (sh.idr) {
+      dpb.clear();
+      DpbPic d; d.frame_id = cur->id; d.frame_num = sh.frame_num;
+      if (sh.long_term_reference) { d.is_long = true; d.long_idx = 0; }
+      dpb.push_back (d);
+      return;
+    }
+    bool cur_long = false; int cur_lidx = -1;
+    if (sh.adaptive_marking) {
+      for (auto& d : dpb) if (!d.is_long) d.frame_num_wrap = d.frame_num > sh.frame_num ? d.frame_num - max_fn : d.frame_num;
+      for (const auto& m : sh.mmco) {
+        const int picx = sh.frame_num - (int) (m.a + 1);
+        if (m.op == 1) { for (size_t i = 0; i < dpb.size(); i++) if (!dpb[i].is_long && dpb[i].frame_num_wrap == picx) { dpb.erase (dpb.begin() + i); break; } }
+        else if (m.op == 2) { for (size_t i = 0; i < dpb.size(); i++) if (dpb[i].is_long && dpb[i].long_idx == (int)m.a) { dpb.erase (dpb.begin() + i); break; } }
+        else if (m.op == 3) {
+          for (size_t i = 0; i < dpb.size(); i++) if (dpb[i].is_long && dpb[i].long_idx == (int)m.b) { dpb.erase (dpb.begin() + i); break; }
+          for (auto& d : dpb) if (!d.is_long && d.frame_num_wrap == picx) { d.is_long = true; d.long_idx = (int)m.b; break; }
+        } else if (m.op == 4) {
+          for (size_t i = 0; i < dpb.size();) { if (dpb[i].is_long && dpb[i].long_idx >= (int)m.a) dpb.erase (dpb.begin() + i); else i++; }
+        } else if (m.op == 5) { dpb.clear(); had_mmco5 = true; }
+        else if (m.op == 6) {
+          for (size_t i = 0; i < dpb.size(); i++) if (dpb[i].is_long && dpb[i].long_idx == (int)m.b) { dpb.erase (dpb.begin() + i); break; }
+          cur_long = true; cur_lidx = (int)m.b;
+        }
+      }
+    } else {
+      const size_t cap = (size_t)std::max (S.num_ref_frames, 1);
+      while (dpb.size() >= cap) {       // sliding window: drop the short-term picture with the smallest FrameNumWrap
+        int best = -1;
+        for (size_t i = 0; i < dpb.size(); i++) {
+          if (dpb[i].is_long) continue;
+          dpb[i].frame_num_wrap = dpb[i].frame_num > sh.frame_num ? dpb[i].frame_num - max_fn : dpb[i].frame_num;
+          if (best < 0 || dpb[i].frame_num_wrap < dpb[best].frame_num_wrap) best = (int)i;
+        }
+        if (best < 0) break;
+        dpb.erase (dpb.begin() + best);
+      }
+    }
+    DpbPic d; d.frame_id = cur->id; d.frame_num = had_mmco5 ? 0 : sh.frame_num; d.is_long = cur_long; d.long_idx = cur_lidx;
+    dpb.push_back (d);
+    const size_t cap = (size_t)std::max (S.num_ref_frames, 1);
+    while (dpb.size() > cap) {          // never exceed the DPB size the stream declared
+      size_t best = 0; bool found = false;
+      for (size_t i = 0; i + 1 < dpb.size(); i++) if (!dpb[i].is_long && (!found || dpb[i].frame_num_wrap < dpb[best].frame_num_wrap)) { best = i; found = true; }
+      dpb.erase (dpb.begin() + (found ? best : 0));
+    }
+  }
+
+  // ---- picture management ---------------------------------------------------------------------------------------
+  void finish_picture() {
+    if (!cur) return;
+    if (first_sh.nal_ref_idc) { mark_reference (first_sh, *csps); cur->is_ref = true; prev_ref_frame_num = had_mmco5 ? 0 : first_sh.frame_num; }
+    had_mmco5 = false;
+    cur->complete = true;
+    self->frames_.push_back (std::move (cur));
+    cur.reset();
+    last_first_mb = -1;
+  }
+
+  void start_picture (const SliceHeader& sh, const Sps& S, const Pps& P) {
+    cur.reset (new FrameOut());
+    cur->id = next_frame_id++;
+    cur->mb_w = S.mb_w; cur->mb_h = S.mb_h; cur->frame_num = sh.frame_num; cur->idr = sh.idr;
+    cur->crop_x = 2 * S.crop_l; cur->crop_y = 2 * S.crop_t;
+    cur->crop_w = S.mb_w * 16 - 2 * (S.crop_l + S.crop_r); cur->crop_h = S.mb_h * 16 - 2 * (S.crop_t + S.crop_b);
+    const size_t n = (size_t)S.mb_w * S.mb_h;
+    cur->mbs.assign (n, lh264_mb_t()); memset (cur->mbs.data(), 0, n * sizeof (lh264_mb_t));
+    cur->coeffs.assign (n * 384, 0); cur->levels.assign (n * 384, 0); cur->covered.assign (n, 0);
+    st.assign (n, MbState());
+    csps = &S; cpps = &P; first_sh = sh;
+    if (sh.idr) { /* the DPB is cleared when the IDR picture is marked */ }
+  }
+
+  // ---- CAVLC residual block (9.2) ------------------------------------------------------------------------------------
+  // returns total_coeff, writes levels in scan order positions start..; -1 on error
+  int residual_block (BitReader& br, int nC, int max_coeff, int* level /*[16] in scan order (index = position in the block's scan)*/) {
+    const int tab = nC < 0 ? 4 : nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3;
+    int total = -1, t1 = 0;
+    if (tab == 3) {                     // 6-bit fixed length code
+      uint32_t v = br.u (6);
+      if (v == 3) { total = 0; t1 = 0; } else { total = (v >> 2) + 1; t1 = v & 3; }
+    } else {
+      const uint32_t bits = br.peek (16);
+      for (int i = 0; i < kCoeffTokenCount[tab]; i++) {
+        const VlcTok& t = kCoeffToken[tab][i];
+        if ((bits >> (16 - t.len)) == t.code) { total = t.total_coeff; t1 = t.trailing_ones; br.skip (t.len); break; }
+      }
+    }
+    for (int i = 0; i < 16; i++) level[i] = 0;
+    if (total < 0 || br.err) return -1;
+    if (total == 0) return 0;
+    if (total > max_coeff) return -1;
+    int lv[16];
+    int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
+    for (int i = 0; i < total; i++) {
+      if (i < t1) { lv[i] = br.u1() ? -1 : 1; continue; }
+      int prefix = 0;
+      while (!br.u1()) { if (br.err || ++prefix > 32) return -1; }
+      int code = std::min (15, prefix) << suffix_len;
+      int ssize = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
+      if (ssize > 0) code += (int)br.u (ssize);
+      if (prefix >= 15 && suffix_len == 0) code += 15;
+      if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+      if (i == t1 && t1 < 3) code += 2;
+      lv[i] = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+      if (suffix_len == 0) suffix_len = 1;
+      if (std::abs (lv[i]) > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+    }
+    int zeros_left = 0;
+    if (total < max_coeff) {
+      const uint32_t bits = br.peek (9);
+      bool ok = false;
+      if (nC < 0) {
+        for (int i = 0; i < kTotalZerosChromaDcCount[total]; i++) {
+          const VlcSym& s = kTotalZerosChromaDc[total][i];
+          if ((bits >> (9 - s.len)) == s.code) { zeros_left = s.sym; br.skip (s.len); ok = true; break; }
+        }
+      } else {
+        for (int i = 0; i < kTotalZerosCount[total]; i++) {
+          const VlcSym& s = kTotalZeros[total][i];
+          if ((bits >> (9 - s.len)) == s.code) { zeros_left = s.sym; br.skip (s.len); ok = true; break; }
+        }
+      }
+      if (!ok) return -1;
+    }
+    if (zeros_left + total > max_coeff) return -1;
+    int pos = zeros_left + total - 1;      // scan position of the highest-frequency coefficient
+    for (int i = 0; i < total; i++) {
+      int run = 0;
+      if (i < total - 1 && zeros_left > 0) {
+        const int zl = std::min (zeros_left, 7);
+        const uint32_t bits = br.peek (11);
+        bool ok = false;
+        for (int k = 0; k < kRunBeforeCount[zl]; k++) {
+          const VlcSym& s = kRunBefore[zl][k];
+          if ((bits >> (11 - s.len)) == s.code) { run = s.sym; br.skip (s.len); ok = true; break; }
+        }
+        if (!ok || run > zeros_left) return -1;
+      } else if (i == total - 1) run = zeros_left;
+      level[pos] = lv[i];
+      pos -= run + 1;
+      zeros_left -= run;
+    }
+    return br.err ? -1 : total;
+  }
+
+  // ---- slice data ---------------------------------------------------------------------------------------------------
+  struct SliceCtx {
+    const Sps* S; const Pps* P; const SliceHeader* sh; int sid;
+    std::vector<int> ref_frames;      // ref_idx -> frame id
+  };
+
+  inline bool mb_avail (int k, int sid) const { return k >= 0 && st[k].slice == sid; }
+  inline bool intra_nb_avail (int k, int sid, bool constrained) const {
+    return mb_avail (k, sid) && (!constrained || st[k].type_class == 1 || st[k].type_class == 2);
+  }
+
+  // total_coeff of the 4x4 block at luma raster position (bx,by may be -1 / 4 meaning the neighbouring MB)
+  int nz_luma (int k, int bx, int by, int sid, bool& avail) const {
+    const int w = cur->mb_w;
+    int kk = k;
+    if (bx < 0) { kk = (k % w) ? k - 1 : -1; bx = 3; }
+    if (by < 0) { kk = k >= w ? k - w : -1; by = 3; }
+    avail = kk == k || mb_avail (kk, sid);
+    if (!avail) return 0;
+    return cur->mbs[kk].nzc[by * 4 + bx];
+  }
+  int nz_chroma (int k, int c, int bx, int by, int sid, bool& avail) const {
+    const int w = cur->mb_w;
+    int kk = k;
+    if (bx < 0) { kk = (k % w) ? k - 1 : -1; bx = 1; }
+    if (by < 0) { kk = k >= w ? k - w : -1; by = 1; }
+    avail = kk == k || mb_avail (kk, sid);
+    if (!avail) return 0;
+    return cur->mbs[kk].nzc[kChromaNzcIdx[c][by * 2 + bx]];
+  }
+  static int nC_of (int nA, bool aA, int nB, bool aB) {
+    if (aA && aB) return (nA + nB + 1) >> 1;
+    if (aA) return nA;
+    if (aB) return nB;
+    return 0;
+  }
+
+  // dequantisation exactly as the reference's parser does it (parse_mb_syn_cavlc.cpp:945-993, :1104-1106)
+  struct Dq { const Pps* P; };
+  inline int dq4 (const Pps& P, bool use_sl, int list, int qp, int j, int level) const {
+    const int x = j & 3, y = j >> 2;
+    const int cls = ((x & 1) == 0 && (y & 1) == 0) ? 0 : ((x & 1) && (y & 1)) ? 1 : 2;
+    const int d = kNormAdjust4x4[qp % 6][cls] << (qp / 6);
+    return use_sl ? (level * (P.sl4[list][j] * d)) >> 4 : level * d;
+  }
+  static inline int cls8 (int x, int y) {
+    if ((x & 3) == 0 && (y & 3) == 0) return 0;
+    if ((x & 1) && (y & 1)) return 1;
+    if ((x & 3) == 2 && (y & 3) == 2) return 2;
+    if (((x & 3) == 0 && (y & 1)) || ((x & 1) && (y & 3) == 0)) return 3;
+    if (((x & 3) == 0 && (y & 3) == 2) || ((x & 3) == 2 && (y & 3) == 0)) return 4;
+    return 5;
+  }
+  inline int dq8 (const Pps& P, bool use_sl, int list8, int qp, int j, int level) const {
+    const int d = (use_sl ? P.sl8[list8][j] : 16) * kNormAdjust8x8[qp % 6][cls8 (j & 7, j >> 3)];
+    return qp >= 36 ? (level * d) << (qp / 6 - 6) : (level * d + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+  }
+
+  // median motion vector prediction (8.4.1.3) on the 4x4-granular state
+  struct Nb { bool avail; int ref; int mvx, mvy; };
+  Nb nb_block (int k, int bx, int by, int sid, uint32_t filled) const {    // bx,by in -1..4 relative to MB k
+    const int w = cur->mb_w;
+    int kk = k, x = bx, y = by;
+    if (x < 0) { kk = (kk % w) ? kk - 1 : -1; x += 4; } else if (x > 3) { kk = ((kk % w) + 1 < w) ? kk + 1 : -1; x -= 4; }
+    if (kk >= 0 && y < 0) { kk = kk >= w ? kk - w : -1; y += 4; }
+    Nb n = {false, -1, 0, 0};
+    if (kk < 0) return n;
+    if (kk == k) {
+      if (bx < 0 || bx > 3 || by < 0) return n;
+      if (!((filled >> (y * 4 + x)) & 1)) return n;
+    } else {
+      if (!mb_avail (kk, sid)) return n;
+      if (kk > k) return n;
+    }
+    n.avail = true;
+    const MbState& s = kk == k ? st[k] : st[kk];
+    n.ref = s.ref[(y >> 1) * 2 + (x >> 1)];
+    n.mvx = s.mv[y * 4 + x][0]; n.mvy = s.mv[y * 4 + x][1];
+    return n;
+  }
+  static int median3 (int a, int b, int c) { return std::max (std::min (a, b), std::min (std::max (a, b), c)); }
+  void predict_mv (int k, int sid, uint32_t filled, int bx, int by, int bw /*in 4x4 units*/, int ref, int shape /*0 generic,1 16x8 top,2 16x8 bottom,3 8x16 left,4 8x16 right*/,
+                   int& px, int& py) const {
+    Nb A = nb_block (k, bx - 1, by, sid, filled), B = nb_block (k, bx, by - 1, sid, filled), C = nb_block (k, bx + bw, by - 1, sid, filled);
+    if (!C.avail) C = nb_block (k, bx - 1, by - 1, sid, filled);
+    if (shape == 1 && B.avail && B.ref == ref) { px = B.mvx; py = B.mvy; return; }
+    if (shape == 2 && A.avail && A.ref == ref) { px = A.mvx; py = A.mvy; return; }
+    if (shape == 3 && A.avail && A.ref == ref) { px = A.mvx; py = A.mvy; return; }
+    if (shape == 4 && C.avail && C.ref == ref) { px = C.mvx; py = C.mvy; return; }
+    if (!B.avail && !C.avail && A.avail) { px = A.mvx; py = A.mvy; return; }
+    const int m = (A.avail && A.ref == ref) + (B.avail && B.ref == ref) + (C.avail && C.ref == ref);
+    if (m == 1) {
+      if (A.avail && A.ref == ref) { px = A.mvx; py = A.mvy; }
+      else if (B.avail && B.ref == ref) { px = B.mvx; py = B.mvy; }
+      else { px = C.mvx; py = C.mvy; }
+      return;
+    }
+    px = median3 (A.avail ? A.mvx : 0, B.avail ? B.mvx : 0, C.avail ? C.mvx : 0);
+    py = median3 (A.avail ? A.mvy : 0, B.avail ? B.mvy : 0, C.avail ? C.mvy : 0);
+  }
+
+  bool parse_slice_data_cavlc (BitReader& br, SliceCtx& c);
+  bool parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_prev, bool is_skip);
+  void finalize_intra_modes (SliceCtx& c, int k, const int* raw4 /*16 raster or null*/, bool is8, int i16mode, int chroma_mode);
+
+  int handle_nal (const uint8_t* nal, size_t len);
+};
+
+// map parsed (standard-numbered) intra modes to the reference's availability-resolved "final" modes
+// (CheckIntraNxNPredMode / CheckIntra16x16PredMode / CheckIntraChromaPredMode, parse_mb_syn_cavlc.cpp:519-611)
+void Parser::Impl::finalize_intra_modes (SliceCtx& c, int k, const int* raw, bool is8, int i16mode, int chroma_mode) {
+  const int w = cur->mb_w, sid = c.sid;
+  const bool cip = c.P->constrained_intra_pred;
+  const bool L = (k % w) && intra_nb_avail (k - 1, sid, cip);
+  const bool T = k >= w && intra_nb_avail (k - w, sid, cip);
+  const bool TL = (k % w) && k >= w && intra_nb_avail (k - w - 1, sid, cip);
+  const bool TR = k >= w && ((k % w) + 1 < w) && intra_nb_avail (k - w + 1, sid, cip);
+  lh264_mb_t& m = cur->mbs[k];
+  m.intra_avail = (uint8_t) ((T ? LH264_AVAIL_T : 0) | (TL ? LH264_AVAIL_TL : 0) | (L ? LH264_AVAIL_L : 0) | (TR ? LH264_AVAIL_TR : 0));
+  auto dcmap = [] (bool l, bool t, int dc, int dcl, int dct, int dc128) { return l && t ? dc : l ? dcl : t ? dct : dc128; };
+  if (raw) {
+    if (!is8) {
+      for (int z = 0; z < 16; z++) {
+        const int bx = z2x (z), by = z2y (z);
+        const bool l = bx > 0 || L, t = by > 0 || T;
+        bool tr;
+        if (by == 0) tr = bx < 3 ? T : TR;
+        else tr = bx < 3 && zidx_before (bx + 1, by - 1, z);
+        int mode = raw[by * 4 + bx];
+        if (mode == 2) mode = dcmap (l, t, LH264_I4_DC, LH264_I4_DC_L, LH264_I4_DC_T, LH264_I4_DC_128);
+        else if (mode == 3 && !tr) mode = LH264_I4_DDL_TOP;
+        else if (mode == 7 && !tr) mode = LH264_I4_VL_TOP;
+        m.intra_mode[by * 4 + bx] = (int8_t)mode;
+      }
+    } else {
+      for (int i8 = 0; i8 < 4; i8++) {
+        const int bx = i8 & 1, by = i8 >> 1;
+        const bool l = bx > 0 || L, t = by > 0 || T;
+        const bool tr = i8 == 0 ? T : i8 == 1 ? TR : i8 == 2;
+        int mode = raw[by * 8 + bx * 2];
+        if (mode == 2) mode = dcmap (l, t, LH264_I4_DC, LH264_I4_DC_L, LH264_I4_DC_T, LH264_I4_DC_128);
+        else if (mode == 3 && !tr) mode = LH264_I4_DDL_TOP;
+        else if (mode == 7 && !tr) mode = LH264_I4_VL_TOP;
+        for (int j = 0; j < 4; j++) m.intra_mode[(by * 2 + (j >> 1)) * 4 + bx * 2 + (j & 1)] = (int8_t)mode;
+      }
+    }
+  } else if (i16mode >= 0) {
+    int mode = i16mode;
+    if (mode == 2) mode = dcmap (L, T, LH264_I16_DC, LH264_I16_DC_L, LH264_I16_DC_T, LH264_I16_DC_128);
+    m.intra_mode[0] = (int8_t)mode;
+  }
+  if (chroma_mode >= 0) {
+    int mode = chroma_mode;
+    if (mode == 0) mode = dcmap (L, T, LH264_C_DC, LH264_C_DC_L, LH264_C_DC_T, LH264_C_DC_128);
+    m.chroma_mode = (int8_t)mode;
+  }
+}
+
+// ---- one macroblock (7.3.5) ------------------------------------------------------------------------------------------
+bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_prev, bool is_skip) {
+  const Sps& S = *c.S; const Pps& P = *c.P; const SliceHeader& sh = *c.sh;
+  const int sid = c.sid, w = cur->mb_w;
+  lh264_mb_t& m = cur->mbs[k];
+  MbState& s = st[k];
+  memset (&m, 0, sizeof (m));
+  m.slice_id = (uint16_t)sid;
+  s.slice = (int16_t)sid;
+  cur->covered[k] = 1;
+  for (int i = 0; i < 16; i++) { s.ipm[i] = 2; s.mv[i][0] = s.mv[i][1] = 0; }
+  for (int i = 0; i < 4; i++) { s.ref[i] = -1; m.ref_idx[i] = -1; }
+  int16_t* coef = &cur->coeffs[(size_t)k * 384];
+  int16_t* lev = &cur->levels[(size_t)k * 384];
+  const bool use_sl = S.scaling_matrix_present || P.scaling_matrix_present;
+  auto set_qp = [&] (int qp) {
+    m.qp_y = (uint8_t)qp;
+    for (int p = 0; p < 2; p++) m.qp_c[p] = kChromaQp[std::min (51, std::max (0, qp + P.chroma_qp_offset[p]))];
+  };
+  auto fill_part = [&] (int bx, int by, int bw, int bh, int ref, int mvx, int mvy, uint32_t& filled) {
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) {
+        s.mv[y * 4 + x][0] = (int16_t)mvx; s.mv[y * 4 + x][1] = (int16_t)mvy;
+        m.mv[y * 4 + x][0] = (int16_t)mvx; m.mv[y * 4 + x][1] = (int16_t)mvy;
+        filled |= 1u << (y * 4 + x);
+      }
+    (void)ref;
+  };
+  if (is_skip) {                                        // P_Skip: inferred motion (8.4.1.1)
+    m.mb_type = LH264_MB_SKIP; s.type_class = 3;
+    for (int i = 0; i < 4; i++) { s.ref[i] = 0; m.ref_idx[i] = 0; }
+    Nb A = nb_block (k, -1, 0, sid, 0), B = nb_block (k, 0, -1, sid, 0);
+    int px = 0, py = 0;
+    if (A.avail && B.avail && !(A.ref == 0 && A.mvx == 0 && A.mvy == 0) && !(B.ref == 0 && B.mvx == 0 && B.mvy == 0))
+      predict_mv (k, sid, 0, 0, 0, 4, 0, 0, px, py);
+    uint32_t filled = 0;
+    fill_part (0, 0, 4, 4, 0, px, py, filled);
+    set_qp (qp_prev);
+    return true;
+  }
+  uint32_t mbt = br.ue();
+  bool intra = true;
+  if (sh.slice_type == 0) { if (mbt < 5) intra = false; else mbt -= 5; }
+  if (br.err) return false;
+  int cbp = 0;
+  bool t8 = false;
+  int raw_modes[16]; bool have_raw = false; int i16mode = -1, chroma_mode = -1;
+  if (intra) {
+    if (mbt > 25) { fail ("invalid mb_type"); return false; }
+    if (mbt == 25) {                                    // I_PCM (7.3.5: pcm alignment + 384 samples)
+      m.mb_type = LH264_MB_IPCM; s.type_class = 2;
+      while (!br.byte_aligned()) br.u1();
+      for (int i = 0; i < 384; i++) coef[i] = (int16_t)br.u (8);
+      m.flags |= LH264_MBF_PCM_IN_COEFF;
+      memset (m.nzc, 16, 24);
+      m.qp_y = 0; m.qp_c[0] = m.qp_c[1] = 0;          // the reference stores QP 0 for I_PCM (decode_slice.cpp:3257-3258)
+      finalize_intra_modes (c, k, nullptr, false, -1, -1);
+      return !br.err;
+    }
+    if (mbt == 0) {                                     // I_NxN
+      if (P.transform_8x8) t8 = br.u1();
+      m.mb_type = t8 ? LH264_MB_I8x8 : LH264_MB_I4x4; s.type_class = 1;
+      const int nblk = t8 ? 4 : 16;
+      for (int i = 0; i < nblk; i++) {
+        const int bx = t8 ? (i & 1) * 2 : z2x (i), by = t8 ? (i >> 1) * 2 : z2y (i);
+        // neighbouring modes (8.3.1.1 / 8.3.2.1)
+        int modeA = 2, modeB = 2; bool dcpred = false;
+        {
+          int kk = k, x = bx - 1, y = by;
+          if (x < 0) { kk = (k % w) ? k - 1 : -1; x = 3; }
+          if (kk != k && !intra_nb_avail (kk, sid, P.constrained_intra_pred)) dcpred = true;
+          else modeA = (kk == k || st[kk].type_class == 1) ? st[kk].ipm[y * 4 + x] : 2;
+        }
+        {
+          int kk = k, x = bx, y = by - 1;
+          if (y < 0) { kk = k >= w ? k - w : -1; y = 3; }
+          if (kk != k && !intra_nb_avail (kk, sid, P.constrained_intra_pred)) dcpred = true;
+          else modeB = (kk == k || st[kk].type_class == 1) ? st[kk].ipm[y * 4 + x] : 2;
+        }
+        const int pred = dcpred ? 2 : std::min (modeA, modeB);
+        int mode = pred;
+        if (!br.u1()) { const int rem = (int)br.u (3); mode = rem < pred ? rem : rem + 1; }
+        const int n = t8 ? 2 : 1;
+        for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) { s.ipm[(by + y) * 4 + bx + x] = (int8_t)mode; raw_modes[(by + y) * 4 + bx + x] = mode; }
+      }
+      have_raw = true;
+      chroma_mode = (int)br.ue();
+      const uint32_t ci = br.ue();
+      if (ci > 47 || chroma_mode > 3) { fail ("invalid cbp / chroma mode"); return false; }
+      cbp = kCbpIntra[ci];
+    } else {                                            // Intra16x16
+      m.mb_type = LH264_MB_I16x16; s.type_class = 2;
+      i16mode = (mbt - 1) & 3;
+      cbp = (((mbt - 1) >> 2) % 3) << 4 | ((mbt - 1) >= 12 ? 15 : 0);
+      chroma_mode = (int)br.ue();
+      if (chroma_mode > 3) { fail ("invalid chroma mode"); return false; }
+    }
+  } else {                                              // P macroblocks
+    s.type_class = 3;
+    static const uint16_t kType[5] = {LH264_MB_P16x16, LH264_MB_P16x8, LH264_MB_P8x16, LH264_MB_P8x8, LH264_MB_P8x8REF0};
+    m.mb_type = kType[mbt];
+    const int nref = sh.num_ref_idx_l0;
+    auto read_ref = [&] () -> int { if (nref <= 1) return 0; if (nref == 2) return br.u1() ? 0 : 1; return (int)br.ue(); };
+    uint32_t filled = 0;
+    if (mbt <= 2) {
+      const int np = mbt == 0 ? 1 : 2;
+      int ref[2];
+      for (int i = 0; i < np; i++) { ref[i] = read_ref(); if (ref[i] >= nref) { fail ("ref_idx out of range"); return false; } }
+      for (int i = 0; i < np; i++) {
+        int bx = 0, by = 0, bw = 4, bh = 4, shape = 0;
+        if (mbt == 1) { bh = 2; by = i * 2; shape = 1 + i; } else if (mbt == 2) { bw = 2; bx = i * 2; shape = 3 + i; }
+        for (int q = 0; q < 4; q++) if ((q >> 1) * 2 >= by && (q >> 1) * 2 < by + bh && (q & 1) * 2 >= bx && (q & 1) * 2 < bx + bw) { s.ref[q] = (int8_t)ref[i]; m.ref_idx[q] = (int8_t)ref[i]; }
+        int px, py;
+        predict_mv (k, sid, filled, bx, by, bw, ref[i], shape, px, py);
+        const int mvx = px + br.se(), mvy = py + br.se();
+        fill_part (bx, by, bw, bh, ref[i], mvx, mvy, filled);
+      }
+    } else {
+      int sub[4], ref[4] = {0, 0, 0, 0};
+      for (int q = 0; q < 4; q++) { sub[q] = (int)br.ue(); if (sub[q] > 3) { fail ("invalid sub_mb_type"); return false; } m.sub_type[q] = (uint8_t) (1 << sub[q]); }
+      if (mbt == 3) for (int q = 0; q < 4; q++) { ref[q] = read_ref(); if (ref[q] >= nref) { fail ("ref_idx out of range"); return false; } }
+      for (int q = 0; q < 4; q++) { s.ref[q] = (int8_t)ref[q]; m.ref_idx[q] = (int8_t)ref[q]; }
+      for (int q = 0; q < 4; q++) {
+        const int qx = (q & 1) * 2, qy = (q >> 1) * 2;
+        const int nsp = sub[q] == 0 ? 1 : sub[q] == 3 ? 4 : 2;
+        for (int j = 0; j < nsp; j++) {
+          int bx = qx, by = qy, bw = 2, bh = 2;
+          if (sub[q] == 1) { bh = 1; by += j; } else if (sub[q] == 2) { bw = 1; bx += j; } else if (sub[q] == 3) { bw = bh = 1; bx += j & 1; by += j >> 1; }
+          int px, py;
+          predict_mv (k, sid, filled, bx, by, bw, ref[q], 0, px, py);
+          const int mvx = px + br.se(), mvy = py + br.se();
+          fill_part (bx, by, bw, bh, ref[q], mvx, mvy, filled);
+        }
+      }
+    }
+    const uint32_t ci = br.ue();
+    if (ci > 47) { fail ("invalid cbp"); return false; }
+    cbp = kCbpInter[ci];
+    bool no_sub_lt8 = true;
+    if (mbt >= 3) for (int q = 0; q < 4; q++) if (m.sub_type[q] != LH264_SUB_8x8) no_sub_lt8 = false;
+    if ((cbp & 15) && P.transform_8x8 && no_sub_lt8) t8 = br.u1();
+  }
+  if (br.err) return false;
+  m.cbp = (uint8_t)cbp;
+  if (t8) m.flags |= LH264_MBF_T8x8;
+  if (intra) finalize_intra_modes (c, k, have_raw ? raw_modes : nullptr, t8, i16mode, chroma_mode);
+  int qp = qp_prev;
+  const bool i16 = m.mb_type == LH264_MB_I16x16;
+  if (cbp || i16) {
+    const int dqp = br.se();
+    if (dqp < -26 || dqp > 25) { fail ("mb_qp_delta out of range"); return false; }
+    qp = ((qp_prev + dqp) % 52 + 52) % 52;
+  }
+  set_qp (qp);
+  qp_prev = qp;
+  if (!(cbp || i16)) return !br.err;
+
+  // ---- residual (7.3.5.3) -------------------------------------------------------------------------------------------
+  int lv[16];
+  const int ylist = intra ? 0 : 3;
+  auto luma_nC = [&] (int bx, int by) { bool aA, aB; const int nA = nz_luma (k, bx - 1, by, sid, aA), nB = nz_luma (k, bx, by - 1, sid, aB); return nC_of (nA, aA, nB, aB); };
+  if (i16) {
+    if (residual_block (br, luma_nC (0, 0), 16, lv) < 0) { fail ("CAVLC error (I16 DC)"); return false; }
+    for (int i = 0; i < 16; i++) if (lv[i]) {
+        const int r = kZigzag4x4[i], zb = xy2z (r & 3, r >> 2);
+        coef[zb * 16] = lev[zb * 16] = (int16_t)lv[i];           // dequantised by the DC transform on the device
+      }
+  }
+  for (int i8 = 0; i8 < 4; i8++) {
+    if (!((cbp >> i8) & 1)) continue;
+    for (int j = 0; j < 4; j++) {
+      const int z = i8 * 4 + j, bx = z2x (z), by = z2y (z);
+      const int maxc = i16 ? 15 : 16;
+      const int tot = residual_block (br, luma_nC (bx, by), maxc, lv);
+      if (tot < 0) { fail ("CAVLC error (luma)"); return false; }
+      m.nzc[by * 4 + bx] = (uint8_t)tot;
+      for (int i = 0; i < maxc; i++) if (lv[i]) {
+          if (t8) {
+            const int pos = kZigzag8x8[4 * i + j];
+            lev[i8 * 64 + pos] = (int16_t)lv[i];
+            coef[i8 * 64 + pos] = (int16_t)dq8 (P, use_sl, intra ? 0 : 1, qp, pos, lv[i]);
+          } else {
+            const int pos = kZigzag4x4[i16 ? i + 1 : i];
+            lev[z * 16 + pos] = (int16_t)lv[i];
+            coef[z * 16 + pos] = (int16_t)dq4 (P, use_sl, ylist, qp, pos, lv[i]);
+          }
+        }
+    }
+  }
+  const int cbpc = cbp >> 4;
+  if (cbpc) {
+    for (int p = 0; p < 2; p++) {                       // chroma DC, nC = -1
+      if (residual_block (br, -1, 4, lv) < 0) { fail ("CAVLC error (chroma DC)"); return false; }
+      const int qc = m.qp_c[p];
+      const int d0 = kNormAdjust4x4[qc % 6][0] << (qc / 6);
+      for (int i = 0; i < 4; i++) if (lv[i]) {
+          lev[256 + p * 64 + i * 16] = (int16_t)lv[i];
+          coef[256 + p * 64 + i * 16] = (int16_t) (use_sl ? (lv[i] * (P.sl4[ylist + 1 + p][0] * d0)) >> 4 : lv[i] * d0);
+        }
+    }
+    if (cbpc == 2) {
+      for (int p = 0; p < 2; p++) for (int j = 0; j < 4; j++) {
+          const int bx = j & 1, by = j >> 1;
+          bool aA, aB;
+          const int nA = nz_chroma (k, p, bx - 1, by, sid, aA), nB = nz_chroma (k, p, bx, by - 1, sid, aB);
+          const int tot = residual_block (br, nC_of (nA, aA, nB, aB), 15, lv);
+          if (tot < 0) { fail ("CAVLC error (chroma AC)"); return false; }
+          m.nzc[kChromaNzcIdx[p][j]] = (uint8_t)tot;
+          for (int i = 0; i < 15; i++) if (lv[i]) {
+              const int pos = kZigzag4x4[i + 1];
+              lev[256 + p * 64 + j * 16 + pos] = (int16_t)lv[i];
+              coef[256 + p * 64 + j * 16 + pos] = (int16_t)dq4 (P, use_sl, ylist + 1 + p, m.qp_c[p], pos, lv[i]);
+            }
+        }
+    }
+  }
+  return !br.err;
+}
+
+bool Parser::Impl::parse_slice_data_cavlc (BitReader& br, SliceCtx& c) {
+  const int n = cur->mb_w * cur->mb_h;
+  int k = c.sh->first_mb, qp_prev = c.sh->slice_qp, count = 0;
+  bool more = true;
+  while (more && k < n) {
+    if (c.sh->slice_type != 2) {
+      uint32_t run = br.ue();
+      if (br.err || (int)run > n - k) { fail ("invalid mb_skip_run"); return false; }
+      for (uint32_t i = 0; i < run; i++, k++, count++) if (!parse_mb_cavlc (br, c, k, qp_prev, true)) return false;
+      more = br.more_rbsp_data();
+      if (!more || k >= n) break;
+    }
+    if (!parse_mb_cavlc (br, c, k, qp_prev, false)) return false;
+    k++; count++;
+    more = br.more_rbsp_data();
+  }
+  cur->slices[c.sid].n_mbs = count;
+  return true;
+}
+
+int Parser::Impl::handle_nal (const uint8_t* nal, size_t len) {
+  if (len < 1) return 0;
+  const int type = nal[0] & 31, ref_idc = (nal[0] >> 5) & 3;
+  if (type == 7 || type == 8 || type == 1 || type == 5) {
+    unescape (nal + 1, len - 1, rbsp);
+    BitReader br; br.init (rbsp.data(), rbsp.size());
+    if (type == 7) { parse_sps (br); return 0; }
+    if (type == 8) { parse_pps (br); return 0; }
+    SliceHeader sh;
+    if (!parse_slice_header (br, type, ref_idc, sh)) return -1;
+    if (sh.redundant_pic_cnt > 0) return 0;
+    const Pps& P = pps[sh.pps_id]; const Sps& S = sps[P.sps_id];
+    if (P.cabac) { self->n_unsupported_++; fail ("CABAC streams are not supported by the host front end yet"); return -1; }
+    const bool new_pic = !cur || sh.frame_num != first_sh.frame_num || sh.idr != first_sh.idr || sh.pps_id != first_sh.pps_id ||
+                         (sh.idr && sh.idr_pic_id != first_sh.idr_pic_id) || ((sh.nal_ref_idc == 0) != (first_sh.nal_ref_idc == 0)) ||
+                         sh.poc_lsb != first_sh.poc_lsb || sh.delta_poc[0] != first_sh.delta_poc[0] || sh.first_mb <= last_first_mb ||
+                         cur->mb_w != S.mb_w || cur->mb_h != S.mb_h;
+    if (new_pic) { finish_picture(); start_picture (sh, S, P); }
+    last_first_mb = sh.first_mb;
+    SliceCtx c; c.S = &S; c.P = &P; c.sh = &sh; c.sid = (int)cur->slices.size();
+    lh264_slice_t sl; memset (&sl, 0, sizeof (sl));
+    sl.first_mb = sh.first_mb; sl.slice_type = (uint8_t)sh.slice_type; sl.deblock_idc = (uint8_t)sh.deblock_idc;
+    sl.alpha_c0_offset = (int8_t)sh.alpha_off; sl.beta_offset = (int8_t)sh.beta_off;
+    sl.n_refs = (uint8_t)sh.num_ref_idx_l0;
+    sl.luma_dc_weight = (S.scaling_matrix_present || P.scaling_matrix_present) ? P.sl4[0][0] : 16;
+    for (int i = 0; i < LH264_MAX_REFS; i++) sl.ref_slot[i] = -1;
+    if (sh.slice_type == 0) {
+      build_ref_list (sh, S, c.ref_frames);
+      for (size_t i = 0; i < c.ref_frames.size() && i < LH264_MAX_REFS; i++) {
+        const int fid = c.ref_frames[i];
+        if (fid < 0) continue;
+        int slot = -1;
+        for (size_t q = 0; q < cur->ref_ids.size(); q++) if (cur->ref_ids[q] == fid) slot = (int)q;
+        if (slot < 0 && cur->ref_ids.size() < LH264_MAX_REFS) { cur->ref_ids.push_back (fid); slot = (int)cur->ref_ids.size() - 1; }
+        sl.ref_slot[i] = (int8_t)slot;
+      }
+      if (sh.has_weights) {
+        sl.weighted_pred = 1; sl.luma_log2_denom = (uint8_t)sh.luma_log2_denom; sl.chroma_log2_denom = (uint8_t)sh.chroma_log2_denom;
+        for (int i = 0; i < LH264_MAX_REFS && i < sh.num_ref_idx_l0; i++) {
+          sl.luma_weight[i] = (int16_t)sh.luma_weight[i]; sl.luma_offset[i] = (int16_t)sh.luma_offset[i];
+          for (int q = 0; q < 2; q++) { sl.chroma_weight[i][q] = (int16_t)sh.chroma_weight[i][q]; sl.chroma_offset[i][q] = (int16_t)sh.chroma_offset[i][q]; }
+        }
+      }
+    }
+    cur->slices.push_back (sl);
+    if (sh.first_mb >= S.mb_w * S.mb_h) { fail ("first_mb_in_slice out of range"); return -1; }
+    if (!parse_slice_data_cavlc (br, c)) return -1;
+    return 0;
+  }
+  if (type == 10 || type == 11) finish_picture();
+  return 0;
+}
+
+Parser::Parser() : d_ (new Impl (this)) {}
+Parser::~Parser() {}
+int Parser::feed_nal (const uint8_t* nal, size_t len) { return d_->handle_nal (nal, len); }
+void Parser::flush() { d_->finish_picture(); }
+
+int Parser::feed (const uint8_t* d, size_t n) {
+  // Annex B: NAL units are delimited by 00 00 01 start codes (B.1)
+  size_t i = 0, start = (size_t) - 1;
+  int rc = 0;
+  while (i + 2 < n) {
+    if (d[i] == 0 && d[i + 1] == 0 && d[i + 2] == 1) {
+      if (start != (size_t) - 1) {
+        size_t end = i;
+        while (end > start && d[end - 1] == 0) end--;     // trailing_zero_8bits / the leading zero of a 4-byte start code
+        if (end > start && feed_nal (d + start, end - start) < 0) rc = -1;
+      }
+      start = i + 3; i += 3;
+    } else i++;
+  }
+  if (start != (size_t) - 1 && start < n) {
+    size_t end = n;
+    while (end > start && d[end - 1] == 0) end--;
+    if (end > start && feed_nal (d + start, end - start) < 0) rc = -1;
+  }
+  return rc;
+}
+
+}  // namespace lh264host

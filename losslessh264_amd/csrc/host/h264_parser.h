@@ -1,0 +1,109 @@
+// h264_parser.h - host front end: Annex-B / NAL / SPS / PPS / slice header / CAVLC macroblock parse producing the flat
+// macroblock records of include/lh264.h.  Fresh implementation from ITU-T H.264; what it
+// must reproduce of the reference is the *content of the records* (the SDqLayer arrays after the reference's parser,
+// dec_frame.h:60-97), which tests compare field by field with oracle/_ref/ref_dump fixtures.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../../include/lh264.h"
+
+namespace lh264host {
+
+struct BitReader {
+  const uint8_t* p = nullptr;
+  size_t nbits = 0, pos = 0;
+  bool err = false;
+  void init (const uint8_t* d, size_t bytes) { p = d; nbits = bytes * 8; pos = 0; err = false; }
+  inline uint32_t u1() { if (pos >= nbits) { err = true; return 0; } uint32_t b = (p[pos >> 3] >> (7 - (pos & 7))) & 1; pos++; return b; }
+  inline uint32_t u (int n) { uint32_t v = 0; while (n-- > 0) v = (v << 1) | u1(); return v; }
+  inline uint32_t peek (int n) const {       // n <= 24, zero-extended past the end
+    uint32_t v = 0; size_t q = pos;
+    for (int i = 0; i < n; i++, q++) v = (v << 1) | (q < nbits ? ((p[q >> 3] >> (7 - (q & 7))) & 1) : 0);
+    return v;
+  }
+  inline void skip (int n) { pos += n; if (pos > nbits) err = true; }
+  uint32_t ue() { int z = 0; while (!u1()) { if (err || ++z > 32) { err = true; return 0; } } return z == 0 ? 0 : ((1u << z) - 1 + u (z)); }
+  int32_t se() { uint32_t k = ue(); return (k & 1) ? (int32_t) ((k + 1) >> 1) : - (int32_t) (k >> 1); }
+  bool byte_aligned() const { return (pos & 7) == 0; }
+  bool more_rbsp_data() const;
+};
+
+struct Sps {
+  bool valid = false;
+  int profile_idc = 0, level_idc = 0, chroma_format_idc = 1;
+  int log2_max_frame_num = 4, poc_type = 0, log2_max_poc_lsb = 4;
+  bool delta_pic_order_always_zero = false;
+  int offset_for_non_ref_pic = 0, offset_for_top_to_bottom = 0, num_ref_frames_in_poc_cycle = 0;
+  std::vector<int> offset_for_ref_frame;
+  int num_ref_frames = 0;
+  bool gaps_allowed = false, frame_mbs_only = true, direct_8x8 = false;
+  int mb_w = 0, mb_h = 0;
+  int crop_l = 0, crop_r = 0, crop_t = 0, crop_b = 0;
+  bool scaling_matrix_present = false;
+  uint8_t sl4[6][16], sl8[2][64];       // raster order, after fall-back rule A
+};
+struct Pps {
+  bool valid = false;
+  int sps_id = 0;
+  bool cabac = false, pic_order_present = false;
+  int num_slice_groups = 1;
+  int num_ref_idx_l0 = 1, num_ref_idx_l1 = 1;
+  bool weighted_pred = false; int weighted_bipred_idc = 0;
+  int pic_init_qp = 26, pic_init_qs = 26, chroma_qp_offset[2] = {0, 0};
+  bool deblocking_control = false, constrained_intra_pred = false, redundant_pic_cnt = false;
+  bool transform_8x8 = false, scaling_matrix_present = false;
+  uint8_t sl4[6][16], sl8[2][64];
+};
+
+struct SliceHeader {
+  int first_mb = 0, slice_type = 0 /*0 P, 2 I*/, pps_id = 0, frame_num = 0, idr_pic_id = 0;
+  int poc_lsb = 0, delta_poc_bottom = 0, delta_poc[2] = {0, 0}, redundant_pic_cnt = 0;
+  int num_ref_idx_l0 = 1;
+  bool idr = false; int nal_ref_idc = 0;
+  struct Reorder { int idc; uint32_t val; };
+  std::vector<Reorder> reorder;
+  bool has_weights = false; int luma_log2_denom = 0, chroma_log2_denom = 0;
+  int luma_weight[32], luma_offset[32], chroma_weight[32][2], chroma_offset[32][2];
+  bool no_output_of_prior = false, long_term_reference = false, adaptive_marking = false;
+  struct Mmco { int op; uint32_t a, b; };
+  std::vector<Mmco> mmco;
+  int cabac_init_idc = 0, slice_qp = 26, deblock_idc = 0, alpha_off = 0, beta_off = 0;
+};
+
+// one parsed picture: exactly what lh264_recon_chains / lh264_ctx_index_chains consume
+struct FrameOut {
+  int id = 0, mb_w = 0, mb_h = 0, frame_num = 0, crop_w = 0, crop_h = 0, crop_x = 0, crop_y = 0;
+  bool idr = false, is_ref = false, complete = false;
+  std::vector<lh264_mb_t> mbs;
+  std::vector<int16_t> coeffs, levels;
+  std::vector<lh264_slice_t> slices;
+  std::vector<int> ref_ids;             // ids of the pictures this one references (its job's ref slots)
+  std::vector<uint8_t> covered;
+};
+
+class Parser {
+ public:
+  Parser();
+  ~Parser();
+  // feed a whole Annex-B byte stream (or a piece that ends on a NAL boundary); completed pictures are appended to frames()
+  int feed (const uint8_t* data, size_t len);
+  int feed_nal (const uint8_t* nal, size_t len);      // one NAL unit without start code (with emulation prevention bytes)
+  void flush();                                        // end of stream: completes the picture in progress
+  std::vector<std::unique_ptr<FrameOut>>& frames() { return frames_; }
+  const std::string& error() const { return err_; }
+  int unsupported_count() const { return n_unsupported_; }
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> d_;
+  std::vector<std::unique_ptr<FrameOut>> frames_;
+  std::string err_;
+  int n_unsupported_ = 0;
+  friend struct Impl;
+};
+
+}  // namespace lh264host

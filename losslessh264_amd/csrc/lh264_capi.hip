@@ -6,6 +6,7 @@
 #include <string.h>
 #include <string>
 #include "../../include/lh264.h"
+#include "host/h264_parser.h"
 
 namespace lh264 {
 __global__ void recon_chain_kernel (const lh264_frame_job_t* jobs, const int32_t* chain_first, int n_chains, int line_bytes);
@@ -168,6 +169,38 @@ double lh264_time_recon_chains (const lh264_frame_job_t* jobs_dev, const int32_t
   hipEventDestroy (a); hipEventDestroy (b);
   return iters > 0 ? (double)ms / iters : 0.0;
 }
+
+// ---- host front end ------------------------------------------------------------------------------------------------
+struct lh264_parser { lh264host::Parser p; };
+lh264_parser_t* lh264_parser_create (void) { return new lh264_parser(); }
+void lh264_parser_destroy (lh264_parser_t* p) { delete p; }
+int lh264_parser_feed (lh264_parser_t* p, const uint8_t* data, size_t len, int flush) {
+  if (!p) return LH264_E_ARG;
+  int rc = (data && len) ? p->p.feed (data, len) : 0;
+  if (flush) p->p.flush();
+  return rc < 0 ? LH264_E_UNSUPPORTED : LH264_OK;
+}
+int lh264_parser_frame_count (const lh264_parser_t* p) { return p ? (int)const_cast<lh264_parser_t*> (p)->p.frames().size() : 0; }
+static const lh264host::FrameOut* pf (const lh264_parser_t* p, int idx) {
+  if (!p) return nullptr;
+  auto& f = const_cast<lh264_parser_t*> (p)->p.frames();
+  return (idx >= 0 && idx < (int)f.size()) ? f[idx].get() : nullptr;
+}
+int lh264_parser_frame_info (const lh264_parser_t* p, int idx, lh264_frame_info_t* o) {
+  const lh264host::FrameOut* f = pf (p, idx);
+  if (!f || !o) return LH264_E_ARG;
+  o->id = f->id; o->mb_w = f->mb_w; o->mb_h = f->mb_h; o->n_slices = (int)f->slices.size(); o->n_refs = (int)f->ref_ids.size();
+  o->frame_num = f->frame_num; o->crop_x = f->crop_x; o->crop_y = f->crop_y; o->crop_w = f->crop_w; o->crop_h = f->crop_h;
+  o->is_ref = f->is_ref; o->idr = f->idr;
+  for (int i = 0; i < LH264_MAX_REFS; i++) o->ref_ids[i] = i < (int)f->ref_ids.size() ? f->ref_ids[i] : -1;
+  return LH264_OK;
+}
+const lh264_mb_t* lh264_parser_frame_mbs (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? f->mbs.data() : nullptr; }
+const int16_t* lh264_parser_frame_coeffs (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? f->coeffs.data() : nullptr; }
+const int16_t* lh264_parser_frame_levels (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? f->levels.data() : nullptr; }
+const lh264_slice_t* lh264_parser_frame_slices (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? f->slices.data() : nullptr; }
+const uint8_t* lh264_parser_frame_covered (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? f->covered.data() : nullptr; }
+const char* lh264_parser_error (const lh264_parser_t* p) { return p ? const_cast<lh264_parser_t*> (p)->p.error().c_str() : ""; }
 
 #ifdef LH264_STAMP
 // diagnostic builds only (not declared in lh264.h)

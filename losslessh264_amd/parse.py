@@ -1,0 +1,44 @@
+"""Host front end binding: Annex-B bytes -> list of frames (numpy views of the parser's records)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class ParsedFrame:
+    pass
+
+
+def parse_stream(data, strict=False):
+    """-> (frames, error_text).  frames have the attributes ReconSession / CtxSession expect."""
+    lib = L.lib()
+    p = lib.lh264_parser_create()
+    try:
+        rc = lib.lh264_parser_feed(p, bytes(data), len(data), 1)
+        err = lib.lh264_parser_error(p).decode()
+        if rc != 0 and strict:
+            raise RuntimeError("h264 parse error: " + err)
+        frames = []
+        info = np.zeros(1, dtype=L.FRAME_INFO_DTYPE)
+        for i in range(lib.lh264_parser_frame_count(p)):
+            L.check(lib.lh264_parser_frame_info(p, i, info.ctypes.data_as(C.c_void_p)))
+            fi = info[0]
+            f = ParsedFrame()
+            f.id, f.mb_w, f.mb_h, f.frame_num = int(fi["id"]), int(fi["mb_w"]), int(fi["mb_h"]), int(fi["frame_num"])
+            f.crop_x, f.crop_y, f.crop_w, f.crop_h = int(fi["crop_x"]), int(fi["crop_y"]), int(fi["crop_w"]), int(fi["crop_h"])
+            f.is_ref, f.idr = bool(fi["is_ref"]), bool(fi["idr"])
+            f.ref_ids = [int(x) for x in fi["ref_ids"][:int(fi["n_refs"])]]
+            n, ns = f.mb_w * f.mb_h, int(fi["n_slices"])
+
+            def arr(ptr, nbytes, dtype):
+                return np.frombuffer(C.string_at(ptr, nbytes), dtype=dtype).copy()
+            f.mbs = arr(lib.lh264_parser_frame_mbs(p, i), n * 128, L.MB_DTYPE)
+            f.coeffs = arr(lib.lh264_parser_frame_coeffs(p, i), n * 768, "<i2").reshape(n, 384)
+            f.levels = arr(lib.lh264_parser_frame_levels(p, i), n * 768, "<i2").reshape(n, 384)
+            f.slices = arr(lib.lh264_parser_frame_slices(p, i), ns * 232, L.SLICE_DTYPE)
+            f.covered = arr(lib.lh264_parser_frame_covered(p, i), n, np.uint8)
+            frames.append(f)
+        return frames, err
+    finally:
+        lib.lh264_parser_destroy(p)

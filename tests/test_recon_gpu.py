@@ -107,3 +107,25 @@ def test_batch_of_streams_and_rerun_idempotent():
     for c in range(sess.n_chains):
         frames = streams[c % len(streams)]
         _compare(sess, c, frames, _oracle_stream(frames), padded=True)
+
+
+def test_parser_to_gpu_sha1():
+    """whole product path: our host front end -> HIP reconstruct -> cropped YUV SHA-1 of the reference's decoder test"""
+    import glob, hashlib, json, os
+    import losslessh264_amd as lh
+    sha = json.load(open(os.path.join(golden_io.GOLDEN_DIR, "decoder_sha1.json")))
+    for path in sorted(glob.glob(os.path.join(golden_io.GOLDEN_DIR, "streams", "*"))):
+        name = os.path.basename(path)
+        if name not in sha:
+            continue
+        frames, err = lh.parse_stream(open(path, "rb").read())
+        assert err == ""
+        sess = lh.ReconSession([frames])
+        sess.run(); sess.synchronize()
+        h = hashlib.sha1()
+        for i, f in enumerate(frames):
+            got = sess.picture(0, i)
+            for p in range(3):
+                s = 1 if p else 0
+                h.update(np.ascontiguousarray(got[p][f.crop_y >> s:(f.crop_y + f.crop_h) >> s, f.crop_x >> s:(f.crop_x + f.crop_w) >> s]).tobytes())
+        assert h.hexdigest() == sha[name], name
