@@ -337,6 +337,7 @@ struct Parser::Impl {
     if (!cur) return;
     if (first_sh.nal_ref_idc) { mark_reference (first_sh, *csps); cur->is_ref = true; prev_ref_frame_num = had_mmco5 ? 0 : first_sh.frame_num; }
     had_mmco5 = false;
+    for (const auto& d : dpb) cur->dpb_ids.push_back (d.frame_id);
     cur->complete = true;
     self->frames_.push_back (std::move (cur));
     cur.reset();
@@ -347,6 +348,7 @@ struct Parser::Impl {
     cur.reset (new FrameOut());
     cur->id = next_frame_id++;
     cur->mb_w = S.mb_w; cur->mb_h = S.mb_h; cur->frame_num = sh.frame_num; cur->idr = sh.idr;
+    cur->idr_pic_id = sh.idr_pic_id; cur->nal_ref_idc = sh.nal_ref_idc;
     cur->crop_x = 2 * S.crop_l; cur->crop_y = 2 * S.crop_t;
     cur->crop_w = S.mb_w * 16 - 2 * (S.crop_l + S.crop_r); cur->crop_h = S.mb_h * 16 - 2 * (S.crop_t + S.crop_b);
     const size_t n = (size_t)S.mb_w * S.mb_h;
@@ -883,6 +885,11 @@ Parser::Parser() : d_ (new Impl (this)) {}
 Parser::~Parser() {}
 int Parser::feed_nal (const uint8_t* nal, size_t len) { return d_->handle_nal (nal, len); }
 void Parser::flush() { d_->finish_picture(); }
+bool Parser::picture_in_progress_is_whole() const {
+  if (!d_->cur) return false;
+  for (uint8_t c : d_->cur->covered) if (!c) return false;
+  return true;
+}
 
 int Parser::feed (const uint8_t* d, size_t n) {
   // Annex B: NAL units are delimited by 00 00 01 start codes (B.1)

@@ -82,6 +82,8 @@ struct FrameOut {
   std::vector<int16_t> coeffs, levels;
   std::vector<lh264_slice_t> slices;
   std::vector<int> ref_ids;             // ids of the pictures this one references (its job's ref slots)
+  std::vector<int> dpb_ids;             // ids still marked 'used for reference' once this picture is done (others may be freed)
+  int idr_pic_id = 0, nal_ref_idc = 0;
   std::vector<uint8_t> covered;
 };
 
@@ -93,8 +95,10 @@ class Parser {
   int feed (const uint8_t* data, size_t len);
   int feed_nal (const uint8_t* nal, size_t len);      // one NAL unit without start code (with emulation prevention bytes)
   void flush();                                        // end of stream: completes the picture in progress
+  bool picture_in_progress_is_whole() const;           // every macroblock of the picture being parsed has been covered by a slice
   std::vector<std::unique_ptr<FrameOut>>& frames() { return frames_; }
-  const std::string& error() const { return err_; }
+  const std::string& error() const { return err_; }       // first error since construction / clear_error()
+  void clear_error() { err_.clear(); }
   int unsupported_count() const { return n_unsupported_; }
 
  private:
