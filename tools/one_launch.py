@@ -17,7 +17,10 @@ elif which == "intra":
 elif which == "720p":
     frames = synth.make_stream(2, 80, 45, 2, p_frames=True)
 s = lh.ReconSession([frames], replicate=streams, share_records=False)
+c = lh.CtxSession([frames], replicate=streams) if which.startswith("ba") else None
 for _ in range(reps):
     s.run()
+    if c is not None:
+        c.run()
 s.synchronize()
 print("mbs per launch", s.n_mbs_total)
