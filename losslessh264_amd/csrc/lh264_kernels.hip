@@ -19,8 +19,11 @@
 //   5. deblocks the macroblock's edges inside the tile              [WelsDeblockingMb deblocking.cpp:815],
 //   6. writes a 16x16 window displaced by (-4,-3) -- the samples that became final in this step: every
 //      output byte is written exactly once -- and publishes the filtered bottom rows.
-// After the last row the workgroup pads the picture (ExpandReferencingPicture) and moves on to the next
-// frame of the chain, which may use it as a reference.
+// Frames of a chain are PIPELINED through the same wavefront: the rows of all frames of the chain form one sequence
+// (global row g is served by wave g % NW), there is no barrier between frames.  A wave that finishes a row also pads
+// the band of picture rows that just became final (ExpandReferencingPicture, row by row) and publishes a per-wave
+// "stored" counter once those HBM stores have completed; a macroblock of the next frame whose motion vectors reach
+// into the frame still in flight waits for exactly the rows it reads.  At most two frames are in flight.
 //
 // Integer work on u8/int16: no MFMA.  Bounds: HBM traffic (1,280 B / intra MB algorithmic) and VALU
 // issue; see DESIGN.md.
@@ -78,9 +81,10 @@ __constant__ uint8_t kTables[52 + 52 + 52 * 4] = {
 
 // ---- workgroup-shared LDS ----------------------------------------------------------------------
 struct WgLds {
-  int      progress[16];
+  int      progress[16];   // per wave: (rows it has started - 1) << 12 | macroblocks finished in its current row
+  int      stored[16];     // per wave: index (among its own rows) of the last row whose HBM stores, including the
+                           // padding that row is responsible for, have completed; -1 = none
   uint8_t  tab[52 + 52 + 208];
-  uint64_t refp[LH264_MAX_REFS][3];    // reference plane pointers of the current job
 };
 
 // ---- per-wave LDS ------------------------------------------------------------------------------
@@ -99,6 +103,8 @@ struct WaveLds {
   uint8_t  bs[32];           // boundary strengths [dir][edge][segment]
   uint8_t  E[32];            // filtered I8x8 edge
   int32_t  S[64];            // DC transform scratch
+  uint64_t refp[LH264_MAX_REFS][3];   // reference plane pointers of this wave's current job
+  int32_t  known_prefix;     // every global row <= known_prefix is known to be stored (cache of wait_prefix)
 };
 
 __device__ __forceinline__ int tY (int r, int c) { return (r + 4) * 32 + (c + 4); }
@@ -204,7 +210,27 @@ struct FrameCtx {
   const GLB lh264_mb_t* mbs; const GLB int16_t* coeffs; const GLB lh264_slice_t* slices;
   GLB uint8_t* dy; GLB uint8_t* du; GLB uint8_t* dv;
   int mb_w, mb_h, sy, sc, flags;
+  // the previous job of the chain (the only other frame that can still be in flight)
+  uint64_t prev_dy;          // its luma plane pointer (0: none)
+  int prev_base, prev_h;     // global index of its row 0, its height in macroblock rows
+  int nw;                    // waves in the workgroup
 };
+
+// Block until every global row <= g_need has been stored (rows are owned round-robin: the next unfinished row of wave
+// w is w + nw * (stored[w] + 1)).
+__device__ __forceinline__ void wait_prefix (const LDS WgLds& G, LDS WaveLds& L, int g_need, int nw) {
+  if (__builtin_amdgcn_readfirstlane (L.known_prefix) >= g_need) return;
+  volatile const LDS int* st = G.stored;
+  for (;;) {
+    int pre = 0x7fffffff;
+    for (int w = 0; w < nw; w++) pre = min (pre, w + nw * (st[w] + 1));
+    pre = __builtin_amdgcn_readfirstlane (pre) - 1;
+    if (pre >= g_need) { L.known_prefix = pre; break; }
+    __builtin_amdgcn_s_sleep (2);
+  }
+  __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+}
+
 
 struct Pref { v2i l, c; uint32_t rec; };   // what is fetched one macroblock ahead (per lane)
 
@@ -702,6 +728,7 @@ __device__ LH264_PHASE void inter_phase (const FrameCtx& F, LDS WaveLds& L, cons
   const int ly = 4 * by + r, lx0 = 4 * bx;
   const int cp = (lane >> 4) & 1, cj = (lane >> 2) & 3;
   const int cy = 4 * (cj >> 1) + r, cx0 = 4 * (cj & 1);
+  int need = -0x7fffffff;
   if (lane < 16) {
     const int qx = lane & 3, qy = lane >> 2;      // raster 4x4 block
     int ox, oy, pw, ph;
@@ -723,6 +750,17 @@ __device__ LH264_PHASE void inter_phase (const FrameCtx& F, LDS WaveLds& L, cons
     L.mvi[lane][1] = cys * F.sc + cxs;
     L.mvi[lane][2] = (fx & 3) | (fy & 3) << 2 | (fx & 7) << 4 | (fy & 7) << 8 | slot << 12 | (ridx < 0 ? 0 : ridx) << 16;
     L.mvi[lane][3] = ox | oy << 8 | pw << 16 | ph << 24;
+    // last luma row this block can touch in the frame that may still be in flight (6-tap reach; covers chroma too)
+    if (L.refp[slot][0] == F.prev_dy) need = syy + 8;
+  }
+  if (F.prev_dy) {
+#pragma unroll
+    for (int msk = 1; msk < 16; msk <<= 1) need = max (need, __shfl_xor (need, msk));
+    need = uni (need);
+    if (need != -0x7fffffff) {
+      const int rneed = clip3 (need >> 4, 0, F.prev_h - 1);
+      wait_prefix (G, L, F.prev_base + min (rneed + 1, F.prev_h - 1), F.nw);
+    }
   }
   wsync();
   const bool wp = sl.weighted() != 0;
@@ -730,7 +768,7 @@ __device__ LH264_PHASE void inter_phase (const FrameCtx& F, LDS WaveLds& L, cons
   {
     const int rb = by * 4 + bx;                     // raster index of this lane's luma block
     const int info = L.mvi[rb][2];
-    const GLB uint8_t* plane = (const GLB uint8_t*)G.refp[(info >> 12) & 15][0];
+    const GLB uint8_t* plane = (const GLB uint8_t*)L.refp[(info >> 12) & 15][0];
     mc_luma_strip (plane + L.mvi[rb][0] + r * F.sy, F.sy, info & 3, (info >> 2) & 3, pr);
     if (wp) {
       const int ri = (info >> 16) & 15, ld = sl.luma_denom(), wt = sl.luma_weight (ri), of = sl.luma_offset (ri);
@@ -748,7 +786,7 @@ __device__ LH264_PHASE void inter_phase (const FrameCtx& F, LDS WaveLds& L, cons
       const int cx = cx0 + 2 * h;
       const int rb = (cy >> 1) * 4 + (cx >> 1);
       const int info = L.mvi[rb][2];
-      const GLB uint8_t* plane = (const GLB uint8_t*)G.refp[(info >> 12) & 15][1 + cp];
+      const GLB uint8_t* plane = (const GLB uint8_t*)L.refp[(info >> 12) & 15][1 + cp];
       mc_chroma_pair (plane + L.mvi[rb][1] + (cy & 1) * F.sc, F.sc, (info >> 4) & 7, (info >> 8) & 7, cpr[2 * h], cpr[2 * h + 1]);
       if (wp) {
         // reference quirk (rec_mb.cpp:309-311): only the top-left (w>>2)x(h>>2) samples of the chroma block are weighted
@@ -1087,29 +1125,49 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// ExpandReferencingPicture (expand_pic.cpp:145-174): every padding sample = nearest picture sample
+// ExpandReferencingPicture (expand_pic.cpp:145-174): every padding sample = nearest picture sample.
+// Done band by band by single waves as the rows of a picture become final.
 // ------------------------------------------------------------------------------------------------
-__device__ void expand_plane (GLB uint8_t* p, int stride, int w, int h, int pad, int tid, int nthreads) {
+// left and right padding of picture rows [r0, r1)
+__device__ void expand_rows (GLB uint8_t* p, int stride, int w, int r0, int r1, int pad, int lane) {
+  const int pd = pad >> 2, wi = w >> 2;
+  for (int i = lane; i < (r1 - r0) * 2 * pd; i += 64) {
+    const int rr = r0 + i / (2 * pd), j = i % (2 * pd);
+    const bool right = j >= pd;
+    const int cd = right ? wi + (j - pd) : j - pd;
+    const uint32_t v = 0x01010101u * p[(size_t)rr * stride + (right ? w - 1 : 0)];
+    * (GLB uint32_t*) (p + (ptrdiff_t)rr * stride + 4 * cd) = v;
+  }
+}
+// the band of `pad` rows above (bottom == false) or below the picture, full padded width
+__device__ void expand_band (GLB uint8_t* p, int stride, int w, int h, int pad, bool bottom, int lane) {
   const int wd = (w + 2 * pad) >> 2, pd = pad >> 2, wi = w >> 2;
-  // top and bottom bands: full padded width
-  for (int i = tid; i < 2 * pad * wd; i += nthreads) {
-    const int band = i / (pad * wd), j = i % (pad * wd);
-    const int rr = band == 0 ? -pad + j / wd : h + j / wd;
-    const int cd = j % wd - pd;
-    const int sr = band == 0 ? 0 : h - 1;
+  const int sr = bottom ? h - 1 : 0;
+  for (int i = lane; i < pad * wd; i += 64) {
+    const int rr = bottom ? h + i / wd : -pad + i / wd;
+    const int cd = i % wd - pd;
     uint32_t v;
     if (cd < 0) v = 0x01010101u * p[(size_t)sr * stride];
     else if (cd >= wi) v = 0x01010101u * p[(size_t)sr * stride + w - 1];
     else v = * (const GLB uint32_t*) (p + (size_t)sr * stride + 4 * cd);
     * (GLB uint32_t*) (p + (ptrdiff_t)rr * stride + 4 * cd) = v;
   }
-  // left and right bands of the picture rows
-  for (int i = tid; i < h * 2 * pd; i += nthreads) {
-    const int rr = i / (2 * pd), j = i % (2 * pd);
-    const bool right = j >= pd;
-    const int cd = right ? wi + (j - pd) : j - pd;
-    const uint32_t v = 0x01010101u * p[(size_t)rr * stride + (right ? w - 1 : 0)];
-    * (GLB uint32_t*) (p + (ptrdiff_t)rr * stride + 4 * cd) = v;
+}
+// padding that depends on macroblock row r only (its samples must be final and visible)
+__device__ __noinline__ void pad_mb_row (const FrameCtx& F, int r, int lane) {
+  const int W = F.mb_w * 16, H = F.mb_h * 16;
+  expand_rows (F.dy, F.sy, W, 16 * r, 16 * r + 16, LH264_PAD_LUMA, lane);
+  expand_rows (F.du, F.sc, W >> 1, 8 * r, 8 * r + 8, LH264_PAD_CHROMA, lane);
+  expand_rows (F.dv, F.sc, W >> 1, 8 * r, 8 * r + 8, LH264_PAD_CHROMA, lane);
+  if (r == 0) {
+    expand_band (F.dy, F.sy, W, H, LH264_PAD_LUMA, false, lane);
+    expand_band (F.du, F.sc, W >> 1, H >> 1, LH264_PAD_CHROMA, false, lane);
+    expand_band (F.dv, F.sc, W >> 1, H >> 1, LH264_PAD_CHROMA, false, lane);
+  }
+  if (r == F.mb_h - 1) {
+    expand_band (F.dy, F.sy, W, H, LH264_PAD_LUMA, true, lane);
+    expand_band (F.du, F.sc, W >> 1, H >> 1, LH264_PAD_CHROMA, true, lane);
+    expand_band (F.dv, F.sc, W >> 1, H >> 1, LH264_PAD_CHROMA, true, lane);
   }
 }
 
@@ -1128,65 +1186,102 @@ recon_chain_kernel (const lh264_frame_job_t* __restrict__ jobs, const int32_t* _
   LDS WaveLds& L = wl[wave];
   const int NL = NW + 1;
   volatile LDS int* progress = G.progress;
+  volatile LDS int* stored = G.stored;
 
   for (int i = tid; i < (int)sizeof (G.tab); i += blockDim.x) G.tab[i] = kTables[i];
+  if (tid < 16) { progress[tid] = 0; stored[tid] = -1; }
+  if (lane == 0) L.known_prefix = -1;
+  __syncthreads();
 
   const int chain = blockIdx.x;
   if (chain >= n_chains) return;
   const int first = chain_first[chain], last = chain_first[chain + 1];
-  for (int ji = first; ji < last; ji++) {
-    const lh264_frame_job_t* J = jobs + ji;
-    FrameCtx F;
-    F.mbs = to_glb<const lh264_mb_t> (J->mbs_dev); F.coeffs = to_glb<const int16_t> (J->coeffs_dev); F.slices = to_glb<const lh264_slice_t> (J->slices_dev);
-    F.dy = to_glb<uint8_t> (J->dst.y_dev); F.du = to_glb<uint8_t> (J->dst.u_dev); F.dv = to_glb<uint8_t> (J->dst.v_dev);
-    F.mb_w = J->mb_w; F.mb_h = J->mb_h; F.sy = J->stride_y; F.sc = J->stride_c; F.flags = J->flags;
-    RowBufs B;
-    B.LY = F.mb_w * 16 + 48; B.LC = F.mb_w * 8 + 24; B.FW = F.mb_w * 16;
-    const int lu = B.LY + 2 * B.LC;
-    if (tid < 16) progress[tid] = 0;
-    if (tid < LH264_MAX_REFS * 3) G.refp[tid / 3][tid % 3] = ((const uint64_t*)&J->ref[tid / 3])[tid % 3];
-    __syncthreads();
-    int jrow = 0, slc_id = -1;
-    STAMP_DECL
-    for (int row = wave; row < F.mb_h; row += NW, jrow++) {
-      LDS uint8_t* cur = slots + (row % NL) * slot_bytes;
-      const LDS uint8_t* top = slots + ((row + NL - 1) % NL) * slot_bytes;
-      B.lineCur = cur; B.lineTop = top; B.fCur = cur + lu; B.fTop = top + lu;
-      const int wprev = (wave + NW - 1) % NW;
-      const int jprev = (row - 1) / NW;
-      Pref pf = prefetch_mb (F, row * F.mb_w, row > 0, lane);
-      for (int x = 0; x < F.mb_w; x++) {
-        Pref nx = pf;
-        if (x + 1 < F.mb_w) nx = prefetch_mb (F, row * F.mb_w + x + 1, row > 0, lane);
-        if (row > 0) {
-          const int need = jprev * F.mb_w + min (x + 2, F.mb_w);
-          while (progress[wprev] < need) __builtin_amdgcn_s_sleep (1);
-          wsync();
-        }
-        STAMP (8);
-#ifdef LH264_STAMP
-        process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, lane, st_t0, st_acc);
-#else
-        process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, lane);
+
+  // this wave's cursor over the chain's rows: global row g = base + row of job ji; the wave owns g == wave (mod NW)
+  int ji = first, row = wave, base = 0, cur_ji = -1;
+  int jw = 0;                               // rows this wave has started so far
+  bool overlap_ok = false;
+  int slc_id = -1;
+  FrameCtx F;
+  F.nw = NW; F.prev_dy = 0; F.prev_base = 0; F.prev_h = 1;
+  RowBufs B;
+  int lu = 0;
+  STAMP_DECL
+  for (;;) {
+    while (ji < last) {
+      const int h = jobs[ji].mb_h;
+      if (row < h) break;
+      row -= h; base += h; ji++;
+    }
+    if (ji >= last) break;
+    if (ji != cur_ji) {                      // entering a new frame
+      const lh264_frame_job_t* J = jobs + ji;
+      F.mbs = to_glb<const lh264_mb_t> (J->mbs_dev); F.coeffs = to_glb<const int16_t> (J->coeffs_dev); F.slices = to_glb<const lh264_slice_t> (J->slices_dev);
+      F.dy = to_glb<uint8_t> (J->dst.y_dev); F.du = to_glb<uint8_t> (J->dst.u_dev); F.dv = to_glb<uint8_t> (J->dst.v_dev);
+      F.mb_w = J->mb_w; F.mb_h = J->mb_h; F.sy = J->stride_y; F.sc = J->stride_c; F.flags = J->flags;
+      B.LY = F.mb_w * 16 + 48; B.LC = F.mb_w * 8 + 24; B.FW = F.mb_w * 16;
+      lu = B.LY + 2 * B.LC;
+      wsync();
+      if (lane < LH264_MAX_REFS * 3) L.refp[lane / 3][lane % 3] = ((const uint64_t*)&J->ref[lane / 3])[lane % 3];
+      overlap_ok = false;
+      F.prev_dy = 0;
+      if (ji > first) {
+        const lh264_frame_job_t* P = J - 1;
+        F.prev_dy = (uint64_t) (uintptr_t)P->dst.y_dev; F.prev_h = P->mb_h; F.prev_base = base - P->mb_h;
+#ifndef LH264_NO_OVERLAP
+        // two frames may be in flight only if this frame's picture is not one the previous frame still reads
+        overlap_ok = true;
+        for (int k = 0; k < LH264_MAX_REFS; k++) overlap_ok = overlap_ok && P->ref[k].y_dev != J->dst.y_dev;
+        overlap_ok = overlap_ok && P->dst.y_dev != J->dst.y_dev;
 #endif
-        if (lane == 0) progress[wave] = jrow * F.mb_w + x + 1;
-        pf = nx;
       }
+      slc_id = -1;
+      cur_ji = ji;
+      wsync();
     }
-    STAMP_FLUSH;
-    // all rows done: make every wave's stores visible, pad the picture, then let the next frame use it
+    // everything older than the previous frame must be complete (and the previous frame too if pictures alias)
+    if (ji > first) wait_prefix (G, L, (overlap_ok ? F.prev_base : base) - 1, NW);
+
+    const int g = base + row;
+    LDS uint8_t* cur = slots + (g % NL) * slot_bytes;
+    const LDS uint8_t* top = slots + ((g + NL - 1) % NL) * slot_bytes;
+    B.lineCur = cur; B.lineTop = top; B.fCur = cur + lu; B.fTop = top + lu;
+    const int wprev = (wave + NW - 1) % NW;
+    const int jprev = row > 0 ? (g - 1 - wprev) / NW : 0;
+    Pref pf = prefetch_mb (F, row * F.mb_w, row > 0, lane);
+    for (int x = 0; x < F.mb_w; x++) {
+      Pref nx = pf;
+      if (x + 1 < F.mb_w) nx = prefetch_mb (F, row * F.mb_w + x + 1, row > 0, lane);
+      if (row > 0) {
+        const int need = (jprev << 12) | min (x + 2, F.mb_w);
+        while ((int) (progress[wprev] - need) < 0) __builtin_amdgcn_s_sleep (1);
+        wsync();
+      }
+      STAMP (8);
+#ifdef LH264_STAMP
+      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, lane, st_t0, st_acc);
+#else
+      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, lane);
+#endif
+      if (lane == 0) progress[wave] = (jw << 12) | (x + 1);
+      pf = nx;
+    }
+    // ---- row end: wait for this row's stores, pad what became final, publish ----------------------------------
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
     if (!(F.flags & LH264_JOB_NO_EXPAND)) {
-      expand_plane (F.dy, F.sy, F.mb_w * 16, F.mb_h * 16, LH264_PAD_LUMA, tid, blockDim.x);
-      expand_plane (F.du, F.sc, F.mb_w * 8, F.mb_h * 8, LH264_PAD_CHROMA, tid, blockDim.x);
-      expand_plane (F.dv, F.sc, F.mb_w * 8, F.mb_h * 8, LH264_PAD_CHROMA, tid, blockDim.x);
+      if (row > 0) {                         // the row above is final now (its last 3 sample rows were written by this wave)
+        while ((int) (stored[wprev] - jprev) < 0) __builtin_amdgcn_s_sleep (1);
+        __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+        pad_mb_row (F, row - 1, lane);
+      }
+      if (row == F.mb_h - 1) pad_mb_row (F, row, lane);
+      __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     }
-    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) stored[wave] = jw;
+    jw++;
+    row += NW;
   }
+  STAMP_FLUSH;
 }
 
 #ifdef LH264_STAMP
