@@ -2,6 +2,7 @@
 // No CPU fallback: every compute entry point fails with LH264_E_NODEVICE when no HIP device is
 // visible.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <string>
@@ -88,6 +89,7 @@ static int pick_waves (int max_mb_w, int max_mb_h, int slot_bytes, size_t* lds_o
   if (inflight > max_mb_h) inflight = max_mb_h;
   int nw = 1;
   while (nw < inflight && nw < 8) nw <<= 1;
+  if (const char* e = getenv ("LH264_WAVES")) { const int v = atoi (e); if (v >= 1 && v <= 8) nw = v; }   // tuning experiments
   for (;;) {
     const size_t lds = lh264::wg_lds_bytes() + lh264::wave_lds_bytes() * nw + (size_t) (nw + 1) * slot_bytes;
     if (lds <= 160 * 1024 || nw == 1) { *lds_out = lds; return nw; }

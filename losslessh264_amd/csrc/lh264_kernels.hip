@@ -45,9 +45,9 @@ namespace lh264 {
 // diagnostic build (-DLH264_STAMP): cycle stamps per phase, summed over all waves into g_stamps (never in product builds)
 #ifdef LH264_STAMP
 __device__ unsigned long long g_stamps[16];
-#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t0; st_t0 = t_; } while (0)
-#define STAMP_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 9; i_++) atomicAdd (&g_stamps[i_], st_acc[i_]); } while (0)
+#define STAMP_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd (&g_stamps[i_], st_acc[i_]); } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i) do {} while (0)
@@ -722,7 +722,7 @@ __device__ __forceinline__ void partition_of (int mb_type, RecView m, int bx, in
 
 // GetInterPred rec_mb.cpp:344-545, BaseMC :247-274, WeightPrediction :276-341 (+ residual add)
 __device__ LH264_PHASE void inter_phase (const FrameCtx& F, LDS WaveLds& L, const LDS WgLds& G, RecView m, SliceView sl, int mb_type,
-                                          int mbx, int mby, int lane) {
+                                          int mbx, int mby, bool has_res, int lane) {
   const int b = lane >> 2, r = lane & 3;
   const int bx = (b & 1) | ((b >> 2) & 1) << 1, by = ((b >> 1) & 1) | ((b >> 3) & 1) << 1;
   const int ly = 4 * by + r, lx0 = 4 * bx;
@@ -776,7 +776,8 @@ __device__ LH264_PHASE void inter_phase (const FrameCtx& F, LDS WaveLds& L, cons
       for (int i = 0; i < 4; i++) pr[i] = clip_u8 (ld >= 1 ? ((pr[i] * wt + (1 << (ld - 1))) >> ld) + of : pr[i] * wt + of);
     }
   }
-  load_res4 (L.R, lane, res);
+  res[0] = res[1] = res[2] = res[3] = 0;
+  if (has_res) load_res4 (L.R, lane, res);
   * (LDS uint32_t*)&L.T[tY (ly, lx0)] = pack_add4 (pr, res);
   if (lane < 32) {
     // chroma strip: plane cp, row cy, cols cx0..cx0+3 = two luma 4x4 blocks wide
@@ -802,7 +803,8 @@ __device__ LH264_PHASE void inter_phase (const FrameCtx& F, LDS WaveLds& L, cons
         }
       }
     }
-    load_res4 (L.R + 256, lane, cres);
+    cres[0] = cres[1] = cres[2] = cres[3] = 0;
+    if (has_res) load_res4 (L.R + 256, lane, cres);
     * (LDS uint32_t*)&L.C[cp][tC (cy, cx0)] = pack_add4 (cpr, cres);
   }
 }
@@ -954,7 +956,7 @@ struct RowBufs {
 };
 
 __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, const LDS WgLds& G, const RowBufs& B, const Pref& pf,
-                                            int mbx, int mby, int par, int& slc_id, int lane
+                                            int mbx, int mby, int par, int& slc_id, bool pub_line, bool pub_left, int lane
 #ifdef LH264_STAMP
                                             , unsigned long long& st_t0, unsigned long long* st_acc
 #endif
@@ -985,15 +987,15 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
   const int cy = 4 * (cj >> 1) + r, cx0 = 4 * (cj & 1);
 
   STAMP (0);
-  // ---- 1. unfiltered neighbours -> tile ------------------------------------------------------
-  if (mby > 0) {
+  // ---- 1. unfiltered neighbours -> tile (only intra prediction reads them) -------------------------
+  if (intra && mby > 0) {
     if (lane < 8) * (LDS uint32_t*)&T[tY (-1, -4 + 4 * lane)] = * (const LDS uint32_t*)&B.lineTop[16 + 16 * mbx - 4 + 4 * lane];
     else if (lane < 16) {
       const int p = (lane - 8) >> 2, q = (lane - 8) & 3;
       * (LDS uint32_t*)&L.C[p][tC (-1, -4 + 4 * q)] = * (const LDS uint32_t*)&B.lineTop[B.LY + p * B.LC + 8 + 8 * mbx - 4 + 4 * q];
     }
   }
-  if (mbx > 0) {
+  if (intra && mbx > 0) {
     if (lane >= 16 && lane < 32) T[tY (lane - 16, -1)] = L.leftY[lane - 16];
     else if (lane >= 32 && lane < 48) { const int p = (lane - 32) >> 3, q = (lane - 32) & 7; L.C[p][tC (q, -1)] = L.leftC[p][q]; }
   }
@@ -1003,11 +1005,12 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
   if (covered) {
     // ---- 2. residual -> R ------------------------------------------------------------------------
     const bool i16 = mb_type == LH264_MB_I16x16;
+    const bool has_res = cbp != 0 || i16;
     if (mb_type != LH264_MB_IPCM) {
-      if (cbp != 0 || i16) {
+      if (has_res) {
         const int dcw = sl.luma_dc_weight();
         residual_phase (L, pf.l, pf.c, mb_type, cbp, t8, m.qp_y(), dcw ? dcw : 16, lane);
-      } else zero_residual (L, lane);
+      } else if (intra) zero_residual (L, lane);
     }
     STAMP (2);
     // ---- 3. prediction + residual -> tile -----------------------------------------------------
@@ -1027,7 +1030,7 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
       else intra4x4_phase (L, m, lane);
       intra_chroma_phase (L, uni (m.chroma_mode()), lane);
     } else if (mb_type & LH264_MB_INTER) {
-      inter_phase (F, L, G, m, sl, mb_type, mbx, mby, lane);
+      inter_phase (F, L, G, m, sl, mb_type, mbx, mby, has_res, lane);
     }
   } else {
     // macroblock not covered by any slice (lost data): pass the picture's current samples through
@@ -1037,12 +1040,16 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
   wsync();
 
   STAMP (3);
-  // ---- 4. publish unfiltered bottom row / right column for later intra prediction ---------------
-  if (lane < 4) * (LDS uint32_t*)&B.lineCur[16 + 16 * mbx + 4 * lane] = * (const LDS uint32_t*)&T[tY (15, 4 * lane)];
-  else if (lane < 8) { const int p = (lane - 4) >> 1, q = (lane - 4) & 1; * (LDS uint32_t*)&B.lineCur[B.LY + p * B.LC + 8 + 8 * mbx + 4 * q] = * (const LDS uint32_t*)&L.C[p][tC (7, 4 * q)]; }
-  else if (lane >= 16 && lane < 32) L.leftY[lane - 16] = T[tY (lane - 16, 15)];
-  else if (lane >= 32 && lane < 48) { const int p = (lane - 32) >> 3, q = (lane - 32) & 7; L.leftC[p][q] = L.C[p][tC (q, 7)]; }
-  wsync();
+  // ---- 4. publish unfiltered bottom row / right column, when an intra macroblock will read them -----
+  if (pub_line) {
+    if (lane < 4) * (LDS uint32_t*)&B.lineCur[16 + 16 * mbx + 4 * lane] = * (const LDS uint32_t*)&T[tY (15, 4 * lane)];
+    else if (lane < 8) { const int p = (lane - 4) >> 1, q = (lane - 4) & 1; * (LDS uint32_t*)&B.lineCur[B.LY + p * B.LC + 8 + 8 * mbx + 4 * q] = * (const LDS uint32_t*)&L.C[p][tC (7, 4 * q)]; }
+  }
+  if (pub_left) {
+    if (lane >= 16 && lane < 32) L.leftY[lane - 16] = T[tY (lane - 16, 15)];
+    else if (lane >= 32 && lane < 48) { const int p = (lane - 32) >> 3, q = (lane - 32) & 7; L.leftC[p][q] = L.C[p][tC (q, 7)]; }
+  }
+  if (pub_line || pub_left) wsync();
 
   STAMP (4);
   // ---- 5. in-loop filter inside the tile ---------------------------------------------------------
@@ -1242,6 +1249,7 @@ recon_chain_kernel (const lh264_frame_job_t* __restrict__ jobs, const int32_t* _
     // everything older than the previous frame must be complete (and the previous frame too if pictures alias)
     if (ji > first) wait_prefix (G, L, (overlap_ok ? F.prev_base : base) - 1, NW);
 
+    STAMP (10);
     const int g = base + row;
     LDS uint8_t* cur = slots + (g % NL) * slot_bytes;
     const LDS uint8_t* top = slots + ((g + NL - 1) % NL) * slot_bytes;
@@ -1249,9 +1257,19 @@ recon_chain_kernel (const lh264_frame_job_t* __restrict__ jobs, const int32_t* _
     const int wprev = (wave + NW - 1) % NW;
     const int jprev = row > 0 ? (g - 1 - wprev) / NW : 0;
     Pref pf = prefetch_mb (F, row * F.mb_w, row > 0, lane);
+    unsigned long long below = 0;            // bit i: macroblock 64*(x/64)+i of the row below is intra
     for (int x = 0; x < F.mb_w; x++) {
       Pref nx = pf;
       if (x + 1 < F.mb_w) nx = prefetch_mb (F, row * F.mb_w + x + 1, row > 0, lane);
+      if ((x & 63) == 0) {
+        int t = 0;
+        if (row + 1 < F.mb_h && x + lane < F.mb_w) t = * (const GLB uint16_t*) (F.mbs + (size_t) (row + 1) * F.mb_w + x + lane);
+        below = __ballot ((t & LH264_MB_INTRA) != 0);
+      }
+      // does an intra macroblock read this one's unfiltered bottom row (below-left, below, below-right) / right column?
+      const int xi = x & 63;
+      const bool pub_line = row + 1 < F.mb_h && (xi == 0 || xi >= 62 || ((below >> (xi - 1)) & 7) != 0);
+      const bool pub_left = x + 1 < F.mb_w && (uni ((int)nx.rec) & LH264_MB_INTRA) != 0;
       if (row > 0) {
         const int need = (jprev << 12) | min (x + 2, F.mb_w);
         while ((int) (progress[wprev] - need) < 0) __builtin_amdgcn_s_sleep (1);
@@ -1259,9 +1277,9 @@ recon_chain_kernel (const lh264_frame_job_t* __restrict__ jobs, const int32_t* _
       }
       STAMP (8);
 #ifdef LH264_STAMP
-      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, lane, st_t0, st_acc);
+      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, pub_line, pub_left, lane, st_t0, st_acc);
 #else
-      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, lane);
+      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, pub_line, pub_left, lane);
 #endif
       if (lane == 0) progress[wave] = (jw << 12) | (x + 1);
       pf = nx;
@@ -1278,6 +1296,7 @@ recon_chain_kernel (const lh264_frame_job_t* __restrict__ jobs, const int32_t* _
       __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     }
     if (lane == 0) stored[wave] = jw;
+    STAMP (9);
     jw++;
     row += NW;
   }

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import golden_io, synth
 import losslessh264_amd as lh
 from losslessh264_amd import _lib
-names = ["0 stage records", "1 neighbours", "2 residual", "3 prediction", "4 publish", "5 deblock loads", "6 deblock filter", "7 window write", "8 wait for row above"]
+names = ["0 stage records", "1 neighbours", "2 residual", "3 prediction", "4 publish", "5 deblock loads", "6 deblock filter", "7 window write", "8 wait for row above", "9 row end (stores+pad)", "10 frame switch/prefix"]
 L = _lib.lib()
 L.lh264_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 16)()
@@ -16,9 +16,9 @@ def run(name, frames, streams):
     L.lh264_debug_read_stamps(buf, 1)
     s.run(); s.synchronize()
     L.lh264_debug_read_stamps(buf, 1)
-    tot = sum(buf[i] for i in range(9))
+    tot = sum(buf[i] for i in range(11))
     print("== %s streams=%d  cycles/MB(sum over phases)=%.0f" % (name, streams, tot / s.n_mbs_total))
-    for i in range(9):
+    for i in range(11):
         print("   %-24s %6.1f%%  %8.0f cyc/MB" % (names[i], 100.0 * buf[i] / tot, buf[i] / s.n_mbs_total))
 ba = golden_io.load("bench_BA_MW_D.264")[:20]
 run("BA_MW_D", ba, 1)
