@@ -616,70 +616,56 @@ __device__ LH264_PHASE void intra_chroma_phase (LDS WaveLds& L, int mode, int la
 // ------------------------------------------------------------------------------------------------
 // motion compensation straight from the padded reference planes (mc.cpp:142-380)
 // ------------------------------------------------------------------------------------------------
-// 12 consecutive bytes starting at (possibly unaligned) p as three dwords
-__device__ __forceinline__ void load12 (const GLB uint8_t* p, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
-  const uintptr_t a = (uintptr_t)p;
-  const GLB uint32_t* q = (const GLB uint32_t*) (a & ~ (uintptr_t)3);
-  const int sh = (int) (a & 3);
-  const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
-  w0 = __builtin_amdgcn_alignbyte (d1, d0, sh);
-  w1 = __builtin_amdgcn_alignbyte (d2, d1, sh);
-  w2 = __builtin_amdgcn_alignbyte (d3, d2, sh);
-}
-__device__ __forceinline__ uint32_t load4 (const GLB uint8_t* p) {
-  const uintptr_t a = (uintptr_t)p;
-  const GLB uint32_t* q = (const GLB uint32_t*) (a & ~ (uintptr_t)3);
-  return __builtin_amdgcn_alignbyte (q[1], q[0], (int) (a & 3));
+// Reference fetches are issued as whole 16-byte (luma) / 8-byte (chroma) aligned rows up front, for every row the
+// macroblock can need, and the interpolation works on registers afterwards: one exposed memory latency per macroblock
+// instead of one per filter stage.  Row12 = 12 consecutive bytes starting at an unaligned address.
+typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+typedef uint32_t v2u __attribute__ ((ext_vector_type (2)));
+struct Row12 { uint32_t w0, w1, w2; };
+__device__ __forceinline__ Row12 align12 (v4u d, int sh) {
+  Row12 o;
+  o.w0 = __builtin_amdgcn_alignbyte (d.y, d.x, sh);
+  o.w1 = __builtin_amdgcn_alignbyte (d.z, d.y, sh);
+  o.w2 = __builtin_amdgcn_alignbyte (d.w, d.z, sh);
+  return o;
 }
 #define BYTE(w, i) (int) (((w) >> (8 * (i))) & 0xff)
-// byte i (0..11) of the 12-byte row {w0,w1,w2}, i compile-time
-#define RB(i) ((i) < 4 ? BYTE (w0, (i)) : (i) < 8 ? BYTE (w1, (i) - 4) : BYTE (w2, (i) - 8))
+// byte i (0..11, compile-time) of a Row12
+#define RB(R, i) ((i) < 4 ? BYTE ((R).w0, (i)) : (i) < 8 ? BYTE ((R).w1, (i) - 4) : BYTE ((R).w2, (i) - 8))
 
-// one 4x1 luma strip; src = integer sample of the strip's first pixel
-__device__ __forceinline__ void mc_luma_strip (const GLB uint8_t* src, int st, int fx, int fy, int out[4]) {
+// one 4x1 luma strip from the fetched rows: R[k] holds samples -2..9 of row k-2 relative to the strip's first sample
+// (McLuma_c / McHorVer* common/src/mc.cpp:142-380).  With fy == 0 only R[2] is defined.
+__device__ __forceinline__ void mc_luma_rows (const Row12 R[6], int fx, int fy, int out[4]) {
   if ((fx | fy) == 0) {
-    const uint32_t w = load4 (src);
 #pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = BYTE (w, i);
+    for (int i = 0; i < 4; i++) out[i] = RB (R[2], i + 2);
     return;
   }
-  if (fy == 0) {                      // a, b, c : one row, bytes -2..6
-    uint32_t w0, w1, w2;
-    load12 (src - 2, w0, w1, w2);
+  if (fy == 0) {                      // a, b, c : one row
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int b = clip_u8 ((tap6 (RB (i), RB (i + 1), RB (i + 2), RB (i + 3), RB (i + 4), RB (i + 5)) + 16) >> 5);
-      out[i] = fx == 2 ? b : (b + (fx == 1 ? RB (i + 2) : RB (i + 3)) + 1) >> 1;
+      const int b = clip_u8 ((tap6 (RB (R[2], i), RB (R[2], i + 1), RB (R[2], i + 2), RB (R[2], i + 3), RB (R[2], i + 4), RB (R[2], i + 5)) + 16) >> 5);
+      out[i] = fx == 2 ? b : (b + (fx == 1 ? RB (R[2], i + 2) : RB (R[2], i + 3)) + 1) >> 1;
     }
     return;
   }
-  if (fx == 0) {                      // d, h, n : six rows, bytes 0..3
-    uint32_t r[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) r[k] = load4 (src + (k - 2) * st);
+  if (fx == 0) {                      // d, h, n : six rows, samples 0..3
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int h = clip_u8 ((tap6 (BYTE (r[0], i), BYTE (r[1], i), BYTE (r[2], i), BYTE (r[3], i), BYTE (r[4], i), BYTE (r[5], i)) + 16) >> 5);
-      out[i] = fy == 2 ? h : (h + (fy == 1 ? BYTE (r[2], i) : BYTE (r[3], i)) + 1) >> 1;
+      const int h = clip_u8 ((tap6 (RB (R[0], i + 2), RB (R[1], i + 2), RB (R[2], i + 2), RB (R[3], i + 2), RB (R[4], i + 2), RB (R[5], i + 2)) + 16) >> 5);
+      out[i] = fy == 2 ? h : (h + (fy == 1 ? RB (R[2], i + 2) : RB (R[3], i + 2)) + 1) >> 1;
     }
     return;
   }
-  // both fractions: vertical 6-tap sums of the 9 columns -2..6 (int16, as the reference keeps them), row by row
-  int vs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  int hh[4] = {0, 0, 0, 0};           // horizontal half-sample of window row 2 (fy==1) or 3 (fy==3)
-  const int hrow = fy == 3 ? 3 : 2;
+  // both fractions: vertical 6-tap sums of the 9 columns -2..6 (int16, as the reference keeps them)
+  int vs[9];
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    uint32_t w0, w1, w2;
-    load12 (src + (k - 2) * st - 2, w0, w1, w2);
-    const int coef = (k == 0 || k == 5) ? 1 : (k == 1 || k == 4) ? -5 : 20;
+  for (int c = 0; c < 9; c++) vs[c] = tap6 (RB (R[0], c), RB (R[1], c), RB (R[2], c), RB (R[3], c), RB (R[4], c), RB (R[5], c));
+  int hh[4];                          // horizontal half-sample of window row 2 (fy==1,2) or 3 (fy==3)
+  Row12 H = R[2];
+  if (fy == 3) H = R[3];
 #pragma unroll
-    for (int c = 0; c < 9; c++) vs[c] += coef * RB (c);
-    if (k == hrow) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) hh[i] = clip_u8 ((tap6 (RB (i), RB (i + 1), RB (i + 2), RB (i + 3), RB (i + 4), RB (i + 5)) + 16) >> 5);
-    }
-  }
+  for (int i = 0; i < 4; i++) hh[i] = clip_u8 ((tap6 (RB (H, i), RB (H, i + 1), RB (H, i + 2), RB (H, i + 3), RB (H, i + 4), RB (H, i + 5)) + 16) >> 5);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int c = i + 2;
@@ -695,11 +681,10 @@ __device__ __forceinline__ void mc_luma_strip (const GLB uint8_t* src, int st, i
   }
 }
 
-// two horizontally adjacent chroma samples sharing one motion vector (a 4x4 luma block = 2x2 chroma)
-__device__ __forceinline__ void mc_chroma_pair (const GLB uint8_t* s, int st, int dx, int dy, int& o0, int& o1) {
-  const uint32_t a = load4 (s);
+// two horizontally adjacent chroma samples sharing one motion vector (a 4x4 luma block = 2x2 chroma); a / b = the
+// 4 bytes starting at the pair's first sample in rows 0 / 1 (McChroma_c mc.cpp)
+__device__ __forceinline__ void mc_chroma_rows (uint32_t a, uint32_t b, int dx, int dy, int& o0, int& o1) {
   if ((dx | dy) == 0) { o0 = BYTE (a, 0); o1 = BYTE (a, 1); return; }
-  const uint32_t b = load4 (s + st);
   const int A = (8 - dx) * (8 - dy), B = dx * (8 - dy), Cc = (8 - dx) * dy, D = dx * dy;
   o0 = (A * BYTE (a, 0) + B * BYTE (a, 1) + Cc * BYTE (b, 0) + D * BYTE (b, 1) + 32) >> 6;
   o1 = (A * BYTE (a, 1) + B * BYTE (a, 2) + Cc * BYTE (b, 1) + D * BYTE (b, 2) + 32) >> 6;
@@ -720,8 +705,13 @@ __device__ __forceinline__ void partition_of (int mb_type, RecView m, int bx, in
   }
 }
 
+// what the inter phase needs of the frame context, passed BY VALUE: a reference to the caller's FrameCtx would turn
+// every field access in this non-inlined function into a scratch load followed by "s_waitcnt vmcnt(0)", which also
+// drains the reference fetches in flight.
+struct InterCtx { uint64_t prev_dy; int sy, sc, mb_w, mb_h, prev_base, prev_h, nw; };
+
 // GetInterPred rec_mb.cpp:344-545, BaseMC :247-274, WeightPrediction :276-341 (+ residual add)
-__device__ LH264_PHASE void inter_phase (const FrameCtx& F, LDS WaveLds& L, const LDS WgLds& G, RecView m, SliceView sl, int mb_type,
+__device__ LH264_PHASE void inter_phase (const InterCtx F, LDS WaveLds& L, const LDS WgLds& G, RecView m, SliceView sl, int mb_type,
                                           int mbx, int mby, bool has_res, int lane) {
   const int b = lane >> 2, r = lane & 3;
   const int bx = (b & 1) | ((b >> 2) & 1) << 1, by = ((b >> 1) & 1) | ((b >> 3) & 1) << 1;
@@ -764,14 +754,58 @@ __device__ LH264_PHASE void inter_phase (const FrameCtx& F, LDS WaveLds& L, cons
   }
   wsync();
   const bool wp = sl.weighted() != 0;
+  // ---- issue every reference fetch of the macroblock ------------------------------------------------------------
+  const int lrb = by * 4 + bx;                      // raster index of this lane's luma block
+  const int linfo = L.mvi[lrb][2];
+  const int lfx = linfo & 3, lfy = (linfo >> 2) & 3;
+  const bool any_fy = __ballot (lfy != 0) != 0;     // wave-uniform: does any strip need the vertical neighbours?
+  v4u lrow[6];
+  int lsh;
+  {
+    const GLB uint8_t* plane = (const GLB uint8_t*)L.refp[(linfo >> 12) & 15][0];
+    const uintptr_t a0 = (uintptr_t) (plane + L.mvi[lrb][0] + r * F.sy - 2);
+    lsh = (int) (a0 & 3);
+    const GLB uint8_t* q = (const GLB uint8_t*) (a0 & ~ (uintptr_t)3);
+#ifdef LH264_ABL_NOMC      // timing ablation only (wrong pictures): no reference fetch
+#pragma unroll
+    for (int k = 0; k < 6; k++) lrow[k] = (v4u) ((uint32_t) (uintptr_t)q);
+#else
+    lrow[2] = * (const GLB v4u*)q;
+    if (any_fy) {
+      lrow[0] = * (const GLB v4u*) (q - 2 * F.sy); lrow[1] = * (const GLB v4u*) (q - F.sy);
+      lrow[3] = * (const GLB v4u*) (q + F.sy); lrow[4] = * (const GLB v4u*) (q + 2 * F.sy); lrow[5] = * (const GLB v4u*) (q + 3 * F.sy);
+    } else lrow[0] = lrow[1] = lrow[3] = lrow[4] = lrow[5] = (v4u) (0u);     // never read (every strip has fy == 0)
+#endif
+  }
+  v2u crow[2][2];                                   // [pair h][row]
+  int cinfo[2], csh[2], crb[2];
+  if (lane < 32) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int cx = cx0 + 2 * h;
+      crb[h] = (cy >> 1) * 4 + (cx >> 1);
+      cinfo[h] = L.mvi[crb[h]][2];
+      const GLB uint8_t* plane = (const GLB uint8_t*)L.refp[(cinfo[h] >> 12) & 15][1 + cp];
+      const uintptr_t a0 = (uintptr_t) (plane + L.mvi[crb[h]][1] + (cy & 1) * F.sc);
+      csh[h] = (int) (a0 & 3);
+      const GLB uint8_t* q = (const GLB uint8_t*) (a0 & ~ (uintptr_t)3);
+#ifdef LH264_ABL_NOMC
+      crow[h][0] = crow[h][1] = (v2u) ((uint32_t) (uintptr_t)q);
+#else
+      crow[h][0] = * (const GLB v2u*)q;
+      crow[h][1] = * (const GLB v2u*) (q + F.sc);
+#endif
+    }
+  }
+  // ---- luma ------------------------------------------------------------------------------------------------------
   int pr[4], res[4];
   {
-    const int rb = by * 4 + bx;                     // raster index of this lane's luma block
-    const int info = L.mvi[rb][2];
-    const GLB uint8_t* plane = (const GLB uint8_t*)L.refp[(info >> 12) & 15][0];
-    mc_luma_strip (plane + L.mvi[rb][0] + r * F.sy, F.sy, info & 3, (info >> 2) & 3, pr);
+    Row12 R[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) R[k] = align12 (lrow[k], lsh);
+    mc_luma_rows (R, lfx, lfy, pr);
     if (wp) {
-      const int ri = (info >> 16) & 15, ld = sl.luma_denom(), wt = sl.luma_weight (ri), of = sl.luma_offset (ri);
+      const int ri = (linfo >> 16) & 15, ld = sl.luma_denom(), wt = sl.luma_weight (ri), of = sl.luma_offset (ri);
 #pragma unroll
       for (int i = 0; i < 4; i++) pr[i] = clip_u8 (ld >= 1 ? ((pr[i] * wt + (1 << (ld - 1))) >> ld) + of : pr[i] * wt + of);
     }
@@ -779,19 +813,19 @@ __device__ LH264_PHASE void inter_phase (const FrameCtx& F, LDS WaveLds& L, cons
   res[0] = res[1] = res[2] = res[3] = 0;
   if (has_res) load_res4 (L.R, lane, res);
   * (LDS uint32_t*)&L.T[tY (ly, lx0)] = pack_add4 (pr, res);
+  // ---- chroma strip: plane cp, row cy, cols cx0..cx0+3 = two luma 4x4 blocks wide ----------------------------------
   if (lane < 32) {
-    // chroma strip: plane cp, row cy, cols cx0..cx0+3 = two luma 4x4 blocks wide
     int cpr[4], cres[4];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int cx = cx0 + 2 * h;
-      const int rb = (cy >> 1) * 4 + (cx >> 1);
-      const int info = L.mvi[rb][2];
-      const GLB uint8_t* plane = (const GLB uint8_t*)L.refp[(info >> 12) & 15][1 + cp];
-      mc_chroma_pair (plane + L.mvi[rb][1] + (cy & 1) * F.sc, F.sc, (info >> 4) & 7, (info >> 8) & 7, cpr[2 * h], cpr[2 * h + 1]);
+      const int info = cinfo[h];
+      const uint32_t a = __builtin_amdgcn_alignbyte (crow[h][0].y, crow[h][0].x, csh[h]);
+      const uint32_t bb = __builtin_amdgcn_alignbyte (crow[h][1].y, crow[h][1].x, csh[h]);
+      mc_chroma_rows (a, bb, (info >> 4) & 7, (info >> 8) & 7, cpr[2 * h], cpr[2 * h + 1]);
       if (wp) {
         // reference quirk (rec_mb.cpp:309-311): only the top-left (w>>2)x(h>>2) samples of the chroma block are weighted
-        const int geo = L.mvi[rb][3];
+        const int geo = L.mvi[crb[h]][3];
         const int pox = (geo & 0xff) >> 1, poy = ((geo >> 8) & 0xff) >> 1, pw = (geo >> 16) & 0xff, ph = (geo >> 24) & 0xff;
         const int ri = (info >> 16) & 15, ld = sl.chroma_denom(), wt = sl.chroma_weight (ri, cp), of = sl.chroma_offset (ri, cp);
 #pragma unroll
@@ -1030,7 +1064,10 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
       else intra4x4_phase (L, m, lane);
       intra_chroma_phase (L, uni (m.chroma_mode()), lane);
     } else if (mb_type & LH264_MB_INTER) {
-      inter_phase (F, L, G, m, sl, mb_type, mbx, mby, has_res, lane);
+      InterCtx ic;
+      ic.prev_dy = F.prev_dy; ic.sy = F.sy; ic.sc = F.sc; ic.mb_w = F.mb_w; ic.mb_h = F.mb_h;
+      ic.prev_base = F.prev_base; ic.prev_h = F.prev_h; ic.nw = F.nw;
+      inter_phase (ic, L, G, m, sl, mb_type, mbx, mby, has_res, lane);
     }
   } else {
     // macroblock not covered by any slice (lost data): pass the picture's current samples through
