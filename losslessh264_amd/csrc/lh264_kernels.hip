@@ -1172,46 +1172,61 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
 // ExpandReferencingPicture (expand_pic.cpp:145-174): every padding sample = nearest picture sample.
 // Done band by band by single waves as the rows of a picture become final.
 // ------------------------------------------------------------------------------------------------
-// left and right padding of picture rows [r0, r1)
-__device__ void expand_rows (GLB uint8_t* p, int stride, int w, int r0, int r1, int pad, int lane) {
-  const int pd = pad >> 2, wi = w >> 2;
-  for (int i = lane; i < (r1 - r0) * 2 * pd; i += 64) {
-    const int rr = r0 + i / (2 * pd), j = i % (2 * pd);
-    const bool right = j >= pd;
-    const int cd = right ? wi + (j - pd) : j - pd;
-    const uint32_t v = 0x01010101u * p[(size_t)rr * stride + (right ? w - 1 : 0)];
-    * (GLB uint32_t*) (p + (ptrdiff_t)rr * stride + 4 * cd) = v;
+// left and right padding of picture rows [r0, r1): every lane replicates one edge sample into 16 (PADW == 32: luma)
+// or 16 (PADW == 16: chroma, the whole side) bytes
+template <int PADW>
+__device__ __forceinline__ void expand_rows (GLB uint8_t* p, int stride, int w, int r0, int r1, int lane) {
+  constexpr int UPS = PADW / 16;                       // 16-byte units per side
+  const int n = (r1 - r0) * 2 * UPS;
+  for (int i = lane; i < n; i += 64) {
+    const int rr = r0 + i / (2 * UPS), j = i % (2 * UPS);
+    const bool right = j >= UPS;
+    GLB uint8_t* row = p + (ptrdiff_t)rr * stride;
+    const uint32_t v = 0x01010101u * row[right ? w - 1 : 0];
+    GLB uint8_t* d = right ? row + w + 16 * (j - UPS) : row - PADW + 16 * j;
+    * (GLB v4u*)d = (v4u) (v);
   }
 }
-// the band of `pad` rows above (bottom == false) or below the picture, full padded width
-__device__ void expand_band (GLB uint8_t* p, int stride, int w, int h, int pad, bool bottom, int lane) {
-  const int wd = (w + 2 * pad) >> 2, pd = pad >> 2, wi = w >> 2;
-  const int sr = bottom ? h - 1 : 0;
-  for (int i = lane; i < pad * wd; i += 64) {
-    const int rr = bottom ? h + i / wd : -pad + i / wd;
-    const int cd = i % wd - pd;
-    uint32_t v;
-    if (cd < 0) v = 0x01010101u * p[(size_t)sr * stride];
-    else if (cd >= wi) v = 0x01010101u * p[(size_t)sr * stride + w - 1];
-    else v = * (const GLB uint32_t*) (p + (size_t)sr * stride + 4 * cd);
-    * (GLB uint32_t*) (p + (ptrdiff_t)rr * stride + 4 * cd) = v;
+// the band of PADW rows above (bottom == false) or below the picture, full padded width.  Each lane owns a column
+// group of sizeof (U) bytes of the source row (replicated edge samples in the corners) and stores it to the band rows.
+template <int PADW, typename U>
+__device__ __forceinline__ void expand_band (GLB uint8_t* p, int stride, int w, int h, bool bottom, int lane) {
+  constexpr int UB = (int)sizeof (U);
+  const int nu = (w + 2 * PADW) / UB;                  // units per padded row
+  const GLB uint8_t* src = p + (ptrdiff_t) (bottom ? h - 1 : 0) * stride;
+  GLB uint8_t* dst0 = p + (ptrdiff_t) (bottom ? h : -PADW) * stride - PADW;
+  const int rpi = nu >= 64 ? 1 : 64 / nu;              // band rows covered by one wave-wide store
+  for (int c0 = 0; c0 < nu; c0 += 64) {
+    const int cu = c0 + (rpi > 1 ? lane % nu : lane);   // this lane's unit
+    const int rsub = rpi > 1 ? lane / nu : 0;
+    const bool act = rpi > 1 ? lane < rpi * nu : cu < nu;
+    U v = (U) (0u);
+    if (act) {
+      const int col = cu * UB - PADW;                  // first picture column of the unit
+      if (col < 0) v = (U) (0x01010101u * src[0]);
+      else if (col >= w) v = (U) (0x01010101u * src[w - 1]);
+      else v = * (const GLB U*) (src + col);
+    }
+    for (int rr = rsub; rr < PADW; rr += rpi)
+      if (act) * (GLB U*) (dst0 + (ptrdiff_t)rr * stride + cu * UB) = v;
   }
 }
+struct PadCtx { GLB uint8_t* dy; GLB uint8_t* du; GLB uint8_t* dv; int sy, sc, mb_w, mb_h; };
 // padding that depends on macroblock row r only (its samples must be final and visible)
-__device__ __noinline__ void pad_mb_row (const FrameCtx& F, int r, int lane) {
+__device__ __noinline__ void pad_mb_row (const PadCtx F, int r, int lane) {
   const int W = F.mb_w * 16, H = F.mb_h * 16;
-  expand_rows (F.dy, F.sy, W, 16 * r, 16 * r + 16, LH264_PAD_LUMA, lane);
-  expand_rows (F.du, F.sc, W >> 1, 8 * r, 8 * r + 8, LH264_PAD_CHROMA, lane);
-  expand_rows (F.dv, F.sc, W >> 1, 8 * r, 8 * r + 8, LH264_PAD_CHROMA, lane);
+  expand_rows<LH264_PAD_LUMA> (F.dy, F.sy, W, 16 * r, 16 * r + 16, lane);
+  expand_rows<LH264_PAD_CHROMA> (F.du, F.sc, W >> 1, 8 * r, 8 * r + 8, lane);
+  expand_rows<LH264_PAD_CHROMA> (F.dv, F.sc, W >> 1, 8 * r, 8 * r + 8, lane);
   if (r == 0) {
-    expand_band (F.dy, F.sy, W, H, LH264_PAD_LUMA, false, lane);
-    expand_band (F.du, F.sc, W >> 1, H >> 1, LH264_PAD_CHROMA, false, lane);
-    expand_band (F.dv, F.sc, W >> 1, H >> 1, LH264_PAD_CHROMA, false, lane);
+    expand_band<LH264_PAD_LUMA, v4u> (F.dy, F.sy, W, H, false, lane);
+    expand_band<LH264_PAD_CHROMA, v2u> (F.du, F.sc, W >> 1, H >> 1, false, lane);
+    expand_band<LH264_PAD_CHROMA, v2u> (F.dv, F.sc, W >> 1, H >> 1, false, lane);
   }
   if (r == F.mb_h - 1) {
-    expand_band (F.dy, F.sy, W, H, LH264_PAD_LUMA, true, lane);
-    expand_band (F.du, F.sc, W >> 1, H >> 1, LH264_PAD_CHROMA, true, lane);
-    expand_band (F.dv, F.sc, W >> 1, H >> 1, LH264_PAD_CHROMA, true, lane);
+    expand_band<LH264_PAD_LUMA, v4u> (F.dy, F.sy, W, H, true, lane);
+    expand_band<LH264_PAD_CHROMA, v2u> (F.du, F.sc, W >> 1, H >> 1, true, lane);
+    expand_band<LH264_PAD_CHROMA, v2u> (F.dv, F.sc, W >> 1, H >> 1, true, lane);
   }
 }
 
@@ -1324,12 +1339,14 @@ recon_chain_kernel (const lh264_frame_job_t* __restrict__ jobs, const int32_t* _
     // ---- row end: wait for this row's stores, pad what became final, publish ----------------------------------
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     if (!(F.flags & LH264_JOB_NO_EXPAND)) {
+      PadCtx pc;
+      pc.dy = F.dy; pc.du = F.du; pc.dv = F.dv; pc.sy = F.sy; pc.sc = F.sc; pc.mb_w = F.mb_w; pc.mb_h = F.mb_h;
       if (row > 0) {                         // the row above is final now (its last 3 sample rows were written by this wave)
         while ((int) (stored[wprev] - jprev) < 0) __builtin_amdgcn_s_sleep (1);
         __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
-        pad_mb_row (F, row - 1, lane);
+        pad_mb_row (pc, row - 1, lane);
       }
-      if (row == F.mb_h - 1) pad_mb_row (F, row, lane);
+      if (row == F.mb_h - 1) pad_mb_row (pc, row, lane);
       __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
     }
     if (lane == 0) stored[wave] = jw;
