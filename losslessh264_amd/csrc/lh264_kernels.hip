@@ -888,96 +888,131 @@ __device__ __forceinline__ int compute_bs (RecView m, RecView nb, bool have_nb, 
   return mv_too ? bs_mv (m, b, m, a) : 0;
 }
 
-// filter one line across an edge.  p points at q0, xs = distance between samples across the edge.
-__device__ __forceinline__ void filter_luma_line (LDS uint8_t* p, int xs, int bs, int alpha, int beta, int tc0) {
-  const int p0 = p[-xs], p1 = p[-2 * xs], p2 = p[-3 * xs], q0 = p[0], q1 = p[xs], q2 = p[2 * xs];
+// Filter one line across one edge, samples in registers.  Luma: DeblockLumaLt4_c / DeblockLumaEq4_c
+// (deblocking_common.cpp:5-83); chroma: DeblockChromaLt4_c / DeblockChromaEq4_c (:85-140), which only touch p0/q0 and
+// use tc0+1.  One routine for both so that the luma lanes (0..15) and the chroma lanes (16..31) of a wave run the same
+// instruction stream.  Every formula uses the samples as they were before this edge.
+__device__ __forceinline__ void filter_edge (int& rp3, int& rp2, int& rp1, int& rp0, int& rq0, int& rq1, int& rq2, int& rq3,
+                                             int bs, int alpha, int beta, int tc0, bool chroma) {
+  if (bs == 0) return;
+  const int p3 = rp3, p2 = rp2, p1 = rp1, p0 = rp0, q0 = rq0, q1 = rq1, q2 = rq2, q3 = rq3;
   const int d = abs (p0 - q0);
   if (!(d < alpha && abs (p1 - p0) < beta && abs (q1 - q0) < beta)) return;
-  if (bs == 4) {                                 // DeblockLumaEq4_c deblocking_common.cpp:39-83
-    if (d < ((alpha >> 2) + 2)) {
-      if (abs (p2 - p0) < beta) {
-        const int p3 = p[-4 * xs];
-        p[-xs] = (uint8_t) ((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
-        p[-2 * xs] = (uint8_t) ((p2 + p1 + p0 + q0 + 2) >> 2);
-        p[-3 * xs] = (uint8_t) ((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
-      } else p[-xs] = (uint8_t) ((2 * p1 + p0 + q1 + 2) >> 2);
-      if (abs (q2 - q0) < beta) {
-        const int q3 = p[3 * xs];
-        p[0] = (uint8_t) ((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
-        p[xs] = (uint8_t) ((p0 + q0 + q1 + q2 + 2) >> 2);
-        p[2 * xs] = (uint8_t) ((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
-      } else p[0] = (uint8_t) ((2 * q1 + q0 + p1 + 2) >> 2);
-    } else {
-      p[-xs] = (uint8_t) ((2 * p1 + p0 + q1 + 2) >> 2);
-      p[0] = (uint8_t) ((2 * q1 + q0 + p1 + 2) >> 2);
-    }
-  } else {                                       // DeblockLumaLt4_c deblocking_common.cpp:5-38
-    int t = tc0;
-    if (abs (p2 - p0) < beta) { p[-2 * xs] = (uint8_t) (p1 + clip3 ((p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1, -tc0, tc0)); t++; }
-    if (abs (q2 - q0) < beta) { p[xs] = (uint8_t) (q1 + clip3 ((q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1, -tc0, tc0)); t++; }
-    const int dl = clip3 ((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -t, t);
-    p[-xs] = (uint8_t)clip_u8 (p0 + dl);
-    p[0] = (uint8_t)clip_u8 (q0 - dl);
-  }
-}
-__device__ __forceinline__ void filter_chroma_line (LDS uint8_t* p, int xs, int bs, int alpha, int beta, int tc) {
-  const int p0 = p[-xs], p1 = p[-2 * xs], q0 = p[0], q1 = p[xs];
-  if (!(abs (p0 - q0) < alpha && abs (p1 - p0) < beta && abs (q1 - q0) < beta)) return;
   if (bs == 4) {
-    p[-xs] = (uint8_t) ((2 * p1 + p0 + q1 + 2) >> 2);
-    p[0] = (uint8_t) ((2 * q1 + q0 + p1 + 2) >> 2);
+    if (!chroma && d < ((alpha >> 2) + 2)) {
+      if (abs (p2 - p0) < beta) {
+        rp0 = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
+        rp1 = (p2 + p1 + p0 + q0 + 2) >> 2;
+        rp2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+      } else rp0 = (2 * p1 + p0 + q1 + 2) >> 2;
+      if (abs (q2 - q0) < beta) {
+        rq0 = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
+        rq1 = (p0 + q0 + q1 + q2 + 2) >> 2;
+        rq2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+      } else rq0 = (2 * q1 + q0 + p1 + 2) >> 2;
+    } else {
+      rp0 = (2 * p1 + p0 + q1 + 2) >> 2;
+      rq0 = (2 * q1 + q0 + p1 + 2) >> 2;
+    }
   } else {
-    const int dl = clip3 ((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
-    p[-xs] = (uint8_t)clip_u8 (p0 + dl);
-    p[0] = (uint8_t)clip_u8 (q0 - dl);
+    int t = tc0;
+    if (chroma) t = tc0 + 1;
+    else {
+      if (abs (p2 - p0) < beta) { rp1 = p1 + clip3 ((p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1, -tc0, tc0); t++; }
+      if (abs (q2 - q0) < beta) { rq1 = q1 + clip3 ((q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1, -tc0, tc0); t++; }
+    }
+    const int dl = clip3 ((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -t, t);
+    rp0 = clip_u8 (p0 + dl);
+    rq0 = clip_u8 (q0 - dl);
   }
 }
 
+// WelsDeblockingMb (deblocking.cpp:815-862) + FilteringEdgeLumaHV / FilteringEdgeChromaHV (:568-700): the macroblock's
+// vertical edges then its horizontal edges, inside the tile.  Lane i < 16 owns luma line i (a row for the vertical
+// edges, a column for the horizontal ones), lanes 16..31 own the 8 lines of Cb and Cr.  A line is loaded once, all its
+// edges are filtered in registers, and it is written back once.
 __device__ LH264_PHASE void deblock_phase (LDS WaveLds& L, const LDS WgLds& G, RecView m, RecView lm, RecView tm, SliceView sl,
                                             bool left_av, bool top_av, int lane) {
   const int mtype = uni (m.mb_type());
-  const bool t8 = uni (m.flags()) & LH264_MBF_T8x8;
   const bool mintra = (mtype == LH264_MB_I4x4 || mtype == LH264_MB_I8x8 || mtype == LH264_MB_I16x16 || mtype == LH264_MB_IPCM);
   if (lane < 32) {
     const int dir = lane >> 4, e = (lane >> 2) & 3, seg = lane & 3;
-    L.bs[lane] = (uint8_t)compute_bs (m, dir == 0 ? lm : tm, dir == 0 ? left_av : top_av, dir, e, seg, mintra);
+    // with the 8x8 transform the luma edges 1 and 3 do not exist (deblocking.cpp:836-849; chroma never uses them)
+    const bool t8 = (m.flags() & LH264_MBF_T8x8) != 0;
+    L.bs[lane] = (t8 && (e & 1)) ? 0 : (uint8_t)compute_bs (m, dir == 0 ? lm : tm, dir == 0 ? left_av : top_av, dir, e, seg, mintra);
   }
   wsync();
-  const int qp = m.qp_y(), qpc0 = m.qp_c (0), qpc1 = m.qp_c (1);
-  const int ao = sl.alpha_off(), bo = sl.beta_off();
+  const v4u bs0 = * (const LDS v4u*)&L.bs[0], bs1 = * (const LDS v4u*)&L.bs[16];     // [edge] = 4 segment bytes
+  const bool any0 = uni ((int) (bs0.x | bs0.y | bs0.z | bs0.w)) != 0, any1 = uni ((int) (bs1.x | bs1.y | bs1.z | bs1.w)) != 0;
+  if ((!any0 && !any1) || lane >= 32) return;
+  const bool chroma = lane >= 16;
+  const int cpl = (lane >> 3) & 1;                  // chroma plane of lanes 16..31
+  const int li = chroma ? (lane & 7) : lane;        // line inside the plane
+  const int sh8 = 8 * (chroma ? (li >> 1) : (li >> 2));   // this line's segment byte inside a bS dword
+  // alpha / beta / tc0 for the three QP cases: inner edges, left macroblock edge, top macroblock edge
   const LDS uint8_t* tab = G.tab;
-  for (int dir = 0; dir < 2; dir++) {
-    const bool have_nb = dir == 0 ? left_av : top_av;
-    const RecView nb = dir == 0 ? lm : tm;
-    for (int e = 0; e < 4; e++) {
-      if (e == 0 && !have_nb) continue;
-      if ((e & 1) && t8) continue;
-      const uint32_t bs4 = * (const LDS uint32_t*)&L.bs[dir * 16 + e * 4];
-      if (uni ((int)bs4) == 0) continue;
-      int q = qp, qc0 = qpc0, qc1 = qpc1;
-      if (e == 0) { q = (qp + nb.qp_y() + 1) >> 1; qc0 = (qpc0 + nb.qp_c (0) + 1) >> 1; qc1 = (qpc1 + nb.qp_c (1) + 1) >> 1; }
-      if (lane < 16) {
-        const int bs = (bs4 >> (8 * (lane >> 2))) & 0xff;
-        const int ia = tab_idx (q + ao);
-        const int alpha = tab[TAB_ALPHA + ia], beta = tab[TAB_BETA + tab_idx (q + bo)];
-        if (bs && (alpha | beta)) {
-          LDS uint8_t* p = dir == 0 ? &L.T[tY (lane, 4 * e)] : &L.T[tY (4 * e, lane)];
-          filter_luma_line (p, dir == 0 ? 1 : 32, bs, alpha, beta, tab[TAB_TC0 + ia * 4 + (bs & 3)]);
-        }
-      } else if (lane < 32 && !(e & 1)) {
-        const int p_ = (lane - 16) >> 3, i = lane & 7;
-        const int bs = (bs4 >> (8 * (i >> 1))) & 0xff;
-        const int qq = p_ ? qc1 : qc0;
-        const int ia = tab_idx (qq + ao);
-        const int alpha = tab[TAB_ALPHA + ia], beta = tab[TAB_BETA + tab_idx (qq + bo)];
-        if (bs && (alpha | beta)) {
-          LDS uint8_t* p = dir == 0 ? &L.C[p_][tC (i, 2 * e)] : &L.C[p_][tC (2 * e, i)];
-          filter_chroma_line (p, dir == 0 ? 1 : 16, bs, alpha, beta, tab[TAB_TC0 + ia * 4 + (bs & 3)] + 1);
-        }
-      }
-      wsync();
+  const int ao = sl.alpha_off(), bo = sl.beta_off();
+  const int qc = chroma ? m.qp_c (cpl) : m.qp_y();
+  const int ql = (qc + (chroma ? lm.qp_c (cpl) : lm.qp_y()) + 1) >> 1;
+  const int qt = (qc + (chroma ? tm.qp_c (cpl) : tm.qp_y()) + 1) >> 1;
+  const int iac = tab_idx (qc + ao), ial = tab_idx (ql + ao), iat = tab_idx (qt + ao);
+  const int alc = tab[TAB_ALPHA + iac], all_ = tab[TAB_ALPHA + ial], alt = tab[TAB_ALPHA + iat];
+  const int bec = tab[TAB_BETA + tab_idx (qc + bo)], bel = tab[TAB_BETA + tab_idx (ql + bo)], bet = tab[TAB_BETA + tab_idx (qt + bo)];
+  const uint32_t tcc = * (const LDS uint32_t*)&tab[TAB_TC0 + 4 * iac], tcl = * (const LDS uint32_t*)&tab[TAB_TC0 + 4 * ial],
+                 tct = * (const LDS uint32_t*)&tab[TAB_TC0 + 4 * iat];
+  int v[20];
+  if (any0) {
+    // ---- vertical edges: line = row li, samples -4..15 (chroma -4..7) ------------------------------------------
+    LDS uint32_t* rowp = (LDS uint32_t*) (chroma ? &L.C[cpl][tC (li, -4)] : &L.T[tY (li, -4)]);
+    uint32_t w[5];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = rowp[k];
+    w[4] = chroma ? 0u : rowp[4];
+#pragma unroll
+    for (int i = 0; i < 20; i++) v[i] = BYTE (w[i >> 2], i & 3);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      // chroma edge k (k < 2) lies on luma edge 2k; chroma has no edges 2, 3
+      const uint32_t bl = k == 0 ? bs0.x : k == 1 ? bs0.y : k == 2 ? bs0.z : bs0.w;
+      const uint32_t bc = k == 0 ? bs0.x : k == 1 ? bs0.z : 0u;
+      const int bs = (int) (((chroma ? bc : bl) >> sh8) & 0xff);
+      const int alpha = k == 0 ? all_ : alc, beta = k == 0 ? bel : bec;
+      const uint32_t tcw = k == 0 ? tcl : tcc;
+      filter_edge (v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], v[4 * k + 4], v[4 * k + 5], v[4 * k + 6], v[4 * k + 7],
+                   (alpha | beta) ? bs : 0, alpha, beta, (int) ((tcw >> (8 * (bs & 3))) & 0xff), chroma);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) w[k] = (uint32_t)v[4 * k] | (uint32_t)v[4 * k + 1] << 8 | (uint32_t)v[4 * k + 2] << 16 | (uint32_t)v[4 * k + 3] << 24;
+#pragma unroll
+    for (int k = 0; k < 3; k++) rowp[k] = w[k];
+    if (!chroma) { rowp[3] = w[3]; rowp[4] = w[4]; }
+  }
+  wsync();
+  if (any1) {
+    // ---- horizontal edges: line = column li, luma rows -4..15 = v[0..19], chroma rows -2..7 = v[2..11] -----------
+    LDS uint8_t* colp = chroma ? &L.C[cpl][tC (-2, li)] : &L.T[tY (-4, li)];
+#pragma unroll
+    for (int i = 0; i < 20; i++) {
+      const int oc = (i < 2 ? 0 : i > 11 ? 9 : i - 2) * 16;
+      v[i] = colp[chroma ? oc : i * 32];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t bl = k == 0 ? bs1.x : k == 1 ? bs1.y : k == 2 ? bs1.z : bs1.w;
+      const uint32_t bc = k == 0 ? bs1.x : k == 1 ? bs1.z : 0u;
+      const int bs = (int) (((chroma ? bc : bl) >> sh8) & 0xff);
+      const int alpha = k == 0 ? alt : alc, beta = k == 0 ? bet : bec;
+      const uint32_t tcw = k == 0 ? tct : tcc;
+      filter_edge (v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], v[4 * k + 4], v[4 * k + 5], v[4 * k + 6], v[4 * k + 7],
+                   (alpha | beta) ? bs : 0, alpha, beta, (int) ((tcw >> (8 * (bs & 3))) & 0xff), chroma);
+    }
+#pragma unroll
+    for (int i = 1; i < 19; i++) {
+      if (i >= 2 && i <= 11) colp[chroma ? (i - 2) * 16 : i * 32] = (uint8_t)v[i];
+      else if (!chroma) colp[i * 32] = (uint8_t)v[i];
     }
   }
+  wsync();
 }
 
 // ------------------------------------------------------------------------------------------------
