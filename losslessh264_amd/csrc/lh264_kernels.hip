@@ -740,8 +740,9 @@ __device__ LH264_PHASE void inter_phase (const InterCtx F, LDS WaveLds& L, const
     L.mvi[lane][1] = cys * F.sc + cxs;
     L.mvi[lane][2] = (fx & 3) | (fy & 3) << 2 | (fx & 7) << 4 | (fy & 7) << 8 | slot << 12 | (ridx < 0 ? 0 : ridx) << 16;
     L.mvi[lane][3] = ox | oy << 8 | pw << 16 | ph << 24;
-    // last luma row this block can touch in the frame that may still be in flight (6-tap reach; covers chroma too)
-    if (L.refp[slot][0] == F.prev_dy) need = syy + 8;
+    // last luma row this block can touch in the frame that may still be in flight: its 4 rows, 3 more under a
+    // vertical 6-tap; chroma: 2 rows, 1 more under a vertical fraction (in luma units)
+    if (L.refp[slot][0] == F.prev_dy) need = max (syy + 3 + ((fy & 3) ? 3 : 0), 2 * (cys + 1 + ((fy & 7) ? 1 : 0)) + 1);
   }
   if (F.prev_dy) {
 #pragma unroll
