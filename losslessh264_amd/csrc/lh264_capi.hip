@@ -11,7 +11,8 @@
 
 namespace lh264 {
 __global__ void recon_chain_kernel (const lh264_frame_job_t* jobs, const int32_t* chain_first, int n_chains, int line_bytes);
-__global__ void ctx_nnz_chain_kernel (const lh264_ctx_job_t* jobs, const int32_t* chain_first, int n_chains);
+__global__ void ctx_nnz_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
+__global__ void ctx_inherit_chain_kernel (const lh264_ctx_job_t* jobs, const int32_t* chain_first, int n_chains);
 __global__ void ctx_symbols_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
 size_t wave_lds_bytes();
 size_t wg_lds_bytes();
@@ -147,9 +148,11 @@ int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chai
   if (!jobs_dev || !chain_first_dev || n_chains < 0 || n_jobs < 0 || max_mbs_per_frame <= 0) return fail (LH264_E_ARG, "bad argument");
   if (n_chains == 0 || n_jobs == 0) return LH264_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL (lh264::ctx_nnz_chain_kernel, dim3 (n_chains), dim3 (256), 0, st, jobs_dev, chain_first_dev, n_chains);
-  HIPCHK (hipGetLastError());
   const int bpj = (max_mbs_per_frame + 3) / 4;
+  hipLaunchKernelGGL (lh264::ctx_nnz_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, n_jobs, bpj);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::ctx_inherit_chain_kernel, dim3 (n_chains), dim3 (256), 0, st, jobs_dev, chain_first_dev, n_chains);
+  HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::ctx_symbols_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, n_jobs, bpj);
   HIPCHK (hipGetLastError());
   return LH264_OK;

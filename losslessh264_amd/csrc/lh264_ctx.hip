@@ -1,13 +1,15 @@
 // lh264_ctx.hip - per-coefficient context-model index kernels.
 //
-// Pass 1  ctx_nnz_chain_kernel : one workgroup per stream, frames in order.  Per macroblock one wave reads the 768 B
-//         of levels coalesced (lane = 4 coefficients of one 4x4 row, as in the reconstruct kernel), counts nonzeros
-//         per 4x4 block across the lane quad and writes the 24-byte entry of the "nnz image"; a skipped macroblock
-//         inherits the PAST entry (FreqImage semantics, decode_slice.cpp:3104-3108).
+// Pass 1a ctx_nnz_kernel       : one wave per coded macroblock, all frames of all streams at once: reads the 768 B of
+//         levels coalesced (lane = 4 coefficients of one 4x4 row), counts nonzeros per 4x4 block across the lane quad
+//         and writes the 24-byte entry of the "nnz image".
+// Pass 1b ctx_inherit_chain_kernel : one workgroup per stream, frames in order: a skipped macroblock inherits the
+//         PAST entry (FreqImage semantics, decode_slice.cpp:3104-3108) - 24 bytes per skipped macroblock.
 // Pass 2  ctx_symbols_kernel   : one wave per macroblock, all frames of all streams at once (context INDICES do not
-//         depend on the adaptive state).  Levels are staged in LDS; one lane per 4x4 block (or per 8x8 block) walks
-//         the zig-zag scan (encode4x4, decode_slice.cpp:2059-2094) producing (prior index, value) pairs, which are
-//         compacted into emission order and written out.
+//         depend on the adaptive state).  Levels are staged in LDS; one lane per 4x4 block (or per 8x8 block) pulls its
+//         levels into registers in scan order (static zig-zag offsets), finds the last nonzero one with a bit mask,
+//         and walks encode4x4's loop (decode_slice.cpp:2059-2094) producing (prior index, value) pairs straight
+//         into the macroblock's emission-order buffer in LDS, which the wave then copies out coalesced.
 // HBM-bound: 768 B + 128 B + 72 B read, ~8 B per coded symbol written.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,44 +32,56 @@ __device__ __forceinline__ int mb_type_code (int t) {       // MacroblockModel::
   }
 }
 
-__constant__ uint8_t kZz16[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
-__constant__ uint8_t kZz64[64] = {
-  0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53,
-  10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63
-};
 
-// ---- pass 1 ---------------------------------------------------------------------------------------------------
+// ---- pass 1a: nonzero counts of every coded macroblock, all frames of all streams at once -----------------------------
 __global__ void __launch_bounds__ (256)
-ctx_nnz_chain_kernel (const lh264_ctx_job_t* __restrict__ jobs, const int32_t* __restrict__ chain_first, int n_chains) {
+ctx_nnz_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int blocks_per_job) {
+  const int ji = blockIdx.x / blocks_per_job;
+  if (ji >= n_jobs) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const lh264_ctx_job_t* J = jobs + ji;
+  const int n = J->mb_w * J->mb_h;
+  const int k = (blockIdx.x % blocks_per_job) * 4 + wave;
+  if (k >= n) return;
+  const int type = __builtin_amdgcn_readfirstlane ((int)as_glb<const lh264_mb_t> (J->mbs_dev)[k].mb_type);
+  if (type == LH264_MB_SKIP || type == 0) return;       // inherited from PAST by pass 1b
+  const GLB int16_t* lv = as_glb<const int16_t> (J->levels_dev) + (size_t)k * 384;
+  GLB uint8_t* cur = as_glb<uint8_t> (J->nnz_cur_dev) + (size_t)k * 24;
+  const v2i a = * (const GLB v2i*) (lv + 4 * lane);
+  v2i b = {0, 0};
+  if (lane < 32) b = * (const GLB v2i*) (lv + 256 + 4 * lane);
+  int c = ((a.x & 0xffff) != 0) + ((a.x >> 16) != 0) + ((a.y & 0xffff) != 0) + ((a.y >> 16) != 0);
+  c += __shfl_xor (c, 1); c += __shfl_xor (c, 2);       // luma block = lane >> 2
+  int d = ((b.x & 0xffff) != 0) + ((b.x >> 16) != 0) + ((b.y & 0xffff) != 0) + ((b.y >> 16) != 0);
+  d += __shfl_xor (d, 1); d += __shfl_xor (d, 2);
+  // gather the 24 counts into 6 dwords: lane 16*j + 4*i holds count 4*j + i
+  const int c0 = __shfl (c, (lane & 3) * 16), c1 = __shfl (c, (lane & 3) * 16 + 4), c2 = __shfl (c, (lane & 3) * 16 + 8), c3 = __shfl (c, (lane & 3) * 16 + 12);
+  const int d0 = __shfl (d, (lane & 1) * 16), d1 = __shfl (d, (lane & 1) * 16 + 4), d2 = __shfl (d, (lane & 1) * 16 + 8), d3 = __shfl (d, (lane & 1) * 16 + 12);
+  if (lane < 4) ((GLB uint32_t*)cur)[lane] = (uint32_t)c0 | (uint32_t)c1 << 8 | (uint32_t)c2 << 16 | (uint32_t)c3 << 24;
+  else if (lane < 6) ((GLB uint32_t*)cur)[lane] = (uint32_t)d0 | (uint32_t)d1 << 8 | (uint32_t)d2 << 16 | (uint32_t)d3 << 24;
+}
+
+// ---- pass 1b: a skipped macroblock inherits the PAST entry (FreqImage semantics, decode_slice.cpp:3104-3108).  The only
+// step that is sequential over the frames of a stream; it moves 24 bytes per skipped macroblock. -------------------------
+__global__ void __launch_bounds__ (256)
+ctx_inherit_chain_kernel (const lh264_ctx_job_t* __restrict__ jobs, const int32_t* __restrict__ chain_first, int n_chains) {
   const int chain = blockIdx.x;
   if (chain >= n_chains) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   for (int ji = chain_first[chain]; ji < chain_first[chain + 1]; ji++) {
     const lh264_ctx_job_t* J = jobs + ji;
     const GLB lh264_mb_t* mbs = as_glb<const lh264_mb_t> (J->mbs_dev);
-    const GLB int16_t* levels = as_glb<const int16_t> (J->levels_dev);
     const GLB uint8_t* past = as_glb<const uint8_t> (J->nnz_past_dev);
     GLB uint8_t* cur = as_glb<uint8_t> (J->nnz_cur_dev);
     const int n = J->mb_w * J->mb_h;
-    for (int k = wave; k < n; k += nw) {
-      const int type = __builtin_amdgcn_readfirstlane ((int)mbs[k].mb_type);
-      if (type == LH264_MB_SKIP || type == 0) {           // rtd.isSkipped: the FreqImage entry is inherited from PAST
-        if (lane < 6) ((GLB uint32_t*) (cur + (size_t)k * 24))[lane] = J->nnz_past_dev ? ((const GLB uint32_t*) (past + (size_t)k * 24))[lane] : 0u;
-        continue;
-      }
-      const GLB int16_t* lv = levels + (size_t)k * 384;
-      const v2i a = * (const GLB v2i*) (lv + 4 * lane);
-      int c = ((a.x & 0xffff) != 0) + ((a.x >> 16) != 0) + ((a.y & 0xffff) != 0) + ((a.y >> 16) != 0);
-      c += __shfl_xor (c, 1); c += __shfl_xor (c, 2);     // luma block = lane >> 2
-      int d = 0;
-      if (lane < 32) {
-        const v2i b = * (const GLB v2i*) (lv + 256 + 4 * lane);
-        d = ((b.x & 0xffff) != 0) + ((b.x >> 16) != 0) + ((b.y & 0xffff) != 0) + ((b.y >> 16) != 0);
-      }
-      d += __shfl_xor (d, 1); d += __shfl_xor (d, 2);
-      if ((lane & 3) == 0) {
-        cur[(size_t)k * 24 + (lane >> 2)] = (uint8_t)c;
-        if (lane < 32) cur[(size_t)k * 24 + 16 + (lane >> 2)] = (uint8_t)d;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+      const int type = mbs[k].mb_type;
+      if (type == LH264_MB_SKIP || type == 0) {
+        GLB uint32_t* d = (GLB uint32_t*) (cur + (size_t)k * 24);
+        if (J->nnz_past_dev) {
+          const GLB uint32_t* sp = (const GLB uint32_t*) (past + (size_t)k * 24);
+          const uint32_t v0 = sp[0], v1 = sp[1], v2 = sp[2], v3 = sp[3], v4 = sp[4], v5 = sp[5];
+          d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3; d[4] = v4; d[5] = v5;
+        } else { d[0] = d[1] = d[2] = d[3] = d[4] = d[5] = 0u; }
       }
     }
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
@@ -80,17 +94,53 @@ ctx_nnz_chain_kernel (const lh264_ctx_job_t* __restrict__ jobs, const int32_t* _
 struct CtxWave {
   int16_t  lv[384];
   uint8_t  nz[4][24];          // cur, left, above, past
-  uint32_t sp[24 * 17];        // staged prior per block (8x8 block i uses the 68 slots of blocks 4i..4i+3)
-  int16_t  sv[24 * 17];
-  int32_t  off[26];            // output offset of: block 0..23, luma DC run (24), chroma DC run (25)
+  uint64_t osym[LH264_CTX_MAX_SYMS];   // the macroblock's symbols in emission order, copied out coalesced
 };
 
-__device__ __forceinline__ void put_sym (GLB lh264_ctx_sym_t* dst, uint32_t prior, int value, int kind) {
-  // {u32 prior, i16 value, u8 kind, u8 pad} as one 8-byte store
-  * (GLB uint64_t*)dst = (uint64_t)prior | ((uint64_t) (uint16_t)value << 32) | ((uint64_t) (uint8_t)kind << 48);
+constexpr uint8_t cZz16[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
+constexpr uint8_t cZz64[64] = {
+  0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53,
+  10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63
+};
+
+__device__ __forceinline__ uint64_t mk_sym (uint32_t prior, int value, int kind) {
+  // {u32 prior, i16 value, u8 kind, u8 pad}
+  return (uint64_t)prior | ((uint64_t) (uint16_t)value << 32) | ((uint64_t) (uint8_t)kind << 48);
 }
 __device__ __forceinline__ int min2 (int v) { return v < 2 ? v : 2; }
 __device__ __forceinline__ int clamp04 (int v) { return v < 0 ? 0 : (v > 4 ? 4 : v); }
+
+// 16 levels of a block in scan order (chunk CH of the 8x8 scan when NCO == 64); static LDS offsets
+template <int NCO, int CH>
+__device__ __forceinline__ void load_scan16 (const LDS int16_t* ac, int c[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) c[i] = ac[NCO == 16 ? cZz16[i] : cZz64[CH * 16 + i]];
+}
+
+struct WalkState { int left_nz, prev, prev2, emitted; };
+
+// encode4x4's coefficient loop (decode_slice.cpp:2059-2094) over scan positions [16*CH, 16*CH+16): every coefficient
+// up to the last nonzero one is a symbol whose prior depends on the two previous levels and the nonzeros left
+template <int CH>
+__device__ __forceinline__ void walk16 (const int c[16], int start, int last, uint32_t outer0, int kind, WalkState& w, LDS uint64_t* dst) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int pos = CH * 16 + i;
+    if (pos >= start && pos <= last) {
+      const uint32_t inner = (uint32_t) ((((min (4, w.left_nz) * 5 + clamp04 (w.prev + 2)) * 5 + clamp04 (w.prev2 + 2)) * 5 + 2) * 5 + 2);
+      dst[w.emitted] = mk_sym ((outer0 + w.emitted) * 3125u + inner, c[i], kind);
+      w.prev2 = w.prev; w.prev = c[i]; w.emitted++;
+      if (c[i]) w.left_nz--;
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t nzmask16 (const int c[16]) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) m |= (uint32_t) (c[i] != 0) << i;
+  return m;
+}
 
 __global__ void __launch_bounds__ (256)
 ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int blocks_per_job) {
@@ -106,15 +156,16 @@ ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int bl
   const GLB lh264_mb_t* m = as_glb<const lh264_mb_t> (J->mbs_dev) + k;
   const GLB int16_t* lv = as_glb<const int16_t> (J->levels_dev) + (size_t)k * 384;
   const GLB uint8_t* cur = as_glb<const uint8_t> (J->nnz_cur_dev);
-  GLB lh264_ctx_sym_t* out = as_glb<lh264_ctx_sym_t> (J->syms_dev) + (size_t)k * LH264_CTX_MAX_SYMS;
+  GLB uint64_t* out = (GLB uint64_t*) (as_glb<lh264_ctx_sym_t> (J->syms_dev) + (size_t)k * LH264_CTX_MAX_SYMS);
   GLB uint16_t* nout = as_glb<uint16_t> (J->n_syms_dev) + k;
 
-  const int type = __builtin_amdgcn_readfirstlane ((int)m->mb_type);
+  const uint32_t head = __builtin_amdgcn_readfirstlane ((int) * (const GLB uint32_t*)m);      // mb_type | cbp << 16 | qp << 24
+  const int type = head & 0xffff;
   if (type == LH264_MB_SKIP || type == LH264_MB_IPCM || type == 0) {     // no coefficient symbols (writeBlock false / PCM)
     if (lane == 0) *nout = 0;
     return;
   }
-  const int cbp = __builtin_amdgcn_readfirstlane ((int)m->cbp);
+  const int cbp = (head >> 16) & 0xff;
   const int t8 = __builtin_amdgcn_readfirstlane ((int)m->flags) & LH264_MBF_T8x8;
   const int sid = __builtin_amdgcn_readfirstlane ((int)m->slice_id);
   const int st = as_glb<const lh264_slice_t> (J->slices_dev)[sid].slice_type;
@@ -139,54 +190,33 @@ ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int bl
   const bool i16 = type == LH264_MB_I16x16;
   const bool cdc = cbpc == 1 || cbpc == 2;
   // one lane per block: 4x4 blocks -> lanes 0..23 ; with the 8x8 transform luma uses lanes 0,4,8,12
-  int cnt = 0;
-  if (lane < 24) {
-    const int b = lane;
-    const bool luma = b < 16;
-    bool coded = luma ? ((cbpl >> (b >> 2)) & 1) : (cbpc == 2);
-    int nco = 16, base = b * 16;
-    if (luma && t8) { coded = coded && ((b & 3) == 0); nco = 64; }
-    if (coded) {
-      const int color = luma ? 0 : (b < 20 ? 1 : 2);
-      const bool emit_dc = luma ? !i16 : !cdc;
-      LDS const uint8_t* C = W.nz[0], *Lf = W.nz[1], *Ab = W.nz[2], *Pa = W.nz[3];
-      int past, left, above;
-      if (luma && t8) {
-        const int s = b >> 2;
-        auto c8 = [] (LDS const uint8_t* p, int i) { return p[i] + p[i + 1] + p[i + 2] + p[i + 3]; };
-        past = c8 (Pa, b);
-        left = (s & 1) == 0 ? c8 (Lf, (s + 1) * 4) : c8 (C, (s - 1) * 4);
-        above = (s & 2) == 0 ? c8 (Ab, (s + 2) * 4) : c8 (C, (s - 2) * 4);
-      } else if (luma) {
-        past = Pa[b];
-        left = (b & 3) == 0 ? Lf[b + 3] : C[b - 1];
-        above = b < 4 ? Ab[b + 12] : C[b - 4];
-      } else {
-        const int i = b - 16;
-        past = Pa[b];
-        left = (i & 1) == 0 ? Lf[b + 1] : C[b - 1];
-        above = (i & 2) == 0 ? Ab[b + 2] : C[b - 2];
-      }
-      LDS const int16_t* ac = W.lv + base;
-      int nonzeros = 0;
-      for (int i = emit_dc ? 0 : 1; i < nco; i++) nonzeros += ac[nco == 16 ? kZz16[i] : kZz64[i]] != 0;
-      LDS uint32_t* sp = W.sp + b * 17;
-      LDS int16_t* sv = W.sv + b * 17;
-      sp[0] = (uint32_t) ((((((st * 16 + mbc) * 3 + color) * 3 + min2 (past)) * 3 + min2 (left)) * 3) + min2 (above));
-      sv[0] = (int16_t)nonzeros;
-      cnt = 1;
-      int left_nz = nonzeros, prev = 0, prev2 = 0, emitted = 0;
-      const uint32_t outer0 = (uint32_t) (((st * 16 + mbc) * 3 + color) * nco);
-      for (int i = emit_dc ? 0 : 1; i < nco && left_nz > 0; i++) {
-        const int c = ac[nco == 16 ? kZz16[i] : kZz64[i]];
-        const uint32_t inner = (uint32_t) ((((min (4, left_nz) * 5 + clamp04 (prev + 2)) * 5 + clamp04 (prev2 + 2)) * 5 + 2) * 5 + 2);
-        sp[cnt] = (outer0 + emitted) * 3125u + inner;
-        sv[cnt] = (int16_t)c;
-        cnt++;
-        prev2 = prev; prev = c; emitted++;
-        if (c) left_nz--;
-      }
+  const int b = lane;
+  const bool luma = b < 16;
+  bool coded = lane < 24 && (luma ? ((cbpl >> (b >> 2)) & 1) : (cbpc == 2));
+  const bool big = luma && t8;
+  if (big) coded = coded && ((b & 3) == 0);
+  const bool emit_dc = luma ? !i16 : !cdc;
+  const int start = emit_dc ? 0 : 1;
+  LDS const int16_t* ac = W.lv + (lane < 24 ? b * 16 : 0);
+  int c[16];
+  int cnt = 0, nonzeros = 0, last = -1;
+  if (coded) {
+    if (!big) {
+      load_scan16<16, 0> (ac, c);
+      const uint32_t mk = nzmask16 (c) & (emit_dc ? 0xffffu : 0xfffeu);
+      nonzeros = __popc (mk);
+      last = 31 - __clz ((int)mk);                     // -1 when mk == 0
+    } else {
+      uint64_t mk = 0;
+      load_scan16<64, 0> (ac, c); mk |= (uint64_t)nzmask16 (c);
+      load_scan16<64, 1> (ac, c); mk |= (uint64_t)nzmask16 (c) << 16;
+      load_scan16<64, 2> (ac, c); mk |= (uint64_t)nzmask16 (c) << 32;
+      load_scan16<64, 3> (ac, c); mk |= (uint64_t)nzmask16 (c) << 48;
+      if (!emit_dc) mk &= ~1ull;
+      nonzeros = __popcll (mk);
+      last = 63 - __clzll ((long long)mk);
     }
+    cnt = 1 + (nonzeros ? last - start + 1 : 0);
   }
   // emission order: luma DC run, chroma DC run, blocks 0..23
   const int ndc_l = i16 ? 16 : 0, ndc_c = cdc ? 8 : 0;
@@ -194,26 +224,54 @@ ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int bl
   for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up (incl, d); if (lane >= d) incl += t; }
   const int total = __shfl (incl, 23) + ndc_l + ndc_c;
   const int my_off = ndc_l + ndc_c + incl - cnt;
-  const int st16 = st;
-  if (lane < 24) {
-    const int b = lane;
-    const uint8_t kind_nz = (b < 16 && t8) ? LH264_SYM_NZ8 : LH264_SYM_NZ4, kind_ac = (b < 16 && t8) ? LH264_SYM_AC8 : LH264_SYM_AC4;
-    LDS const uint32_t* sp = W.sp + b * 17;
-    LDS const int16_t* sv = W.sv + b * 17;
-    for (int j = 0; j < cnt; j++) {
-      put_sym (out + my_off + j, sp[j], sv[j], j == 0 ? kind_nz : kind_ac);
+  if (coded) {
+    const int color = luma ? 0 : (b < 20 ? 1 : 2);
+    LDS const uint8_t* C = W.nz[0], *Lf = W.nz[1], *Ab = W.nz[2], *Pa = W.nz[3];
+    int past, left, above;
+    if (big) {
+      const int s = b >> 2;
+      auto c8 = [] (LDS const uint8_t* p, int i) { return p[i] + p[i + 1] + p[i + 2] + p[i + 3]; };
+      past = c8 (Pa, b);
+      left = (s & 1) == 0 ? c8 (Lf, (s + 1) * 4) : c8 (C, (s - 1) * 4);
+      above = (s & 2) == 0 ? c8 (Ab, (s + 2) * 4) : c8 (C, (s - 2) * 4);
+    } else if (luma) {
+      past = Pa[b];
+      left = (b & 3) == 0 ? Lf[b + 3] : C[b - 1];
+      above = b < 4 ? Ab[b + 12] : C[b - 4];
+    } else {
+      const int i = b - 16;
+      past = Pa[b];
+      left = (i & 1) == 0 ? Lf[b + 1] : C[b - 1];
+      above = (i & 2) == 0 ? Ab[b + 2] : C[b - 2];
     }
-  } else if (lane >= 32 && lane < 48) {
+    LDS uint64_t* dst = W.osym + my_off;
+    const int nco = big ? 64 : 16;
+    dst[0] = mk_sym ((uint32_t) ((((((st * 16 + mbc) * 3 + color) * 3 + min2 (past)) * 3 + min2 (left)) * 3) + min2 (above)), nonzeros,
+                     big ? LH264_SYM_NZ8 : LH264_SYM_NZ4);
+    const uint32_t outer0 = (uint32_t) (((st * 16 + mbc) * 3 + color) * nco);
+    WalkState w = {nonzeros, 0, 0, 0};
+    if (!big) walk16<0> (c, start, last, outer0, LH264_SYM_AC4, w, dst + 1);
+    else {
+      load_scan16<64, 0> (ac, c); walk16<0> (c, start, last, outer0, LH264_SYM_AC8, w, dst + 1);
+      load_scan16<64, 1> (ac, c); walk16<1> (c, start, last, outer0, LH264_SYM_AC8, w, dst + 1);
+      load_scan16<64, 2> (ac, c); walk16<2> (c, start, last, outer0, LH264_SYM_AC8, w, dst + 1);
+      load_scan16<64, 3> (ac, c); walk16<3> (c, start, last, outer0, LH264_SYM_AC8, w, dst + 1);
+    }
+  }
+  if (lane >= 32 && lane < 48) {
     if (i16) {                                       // getLumaDCIntPrior: lumaDCIntPriors[i][slice][mbtype]
       const int i = lane - 32;
-      put_sym (out + i, (uint32_t) ((i * 5 + st16) * 16 + mbc), W.lv[i * 16], LH264_SYM_LUMA_DC);
+      W.osym[i] = mk_sym ((uint32_t) ((i * 5 + st) * 16 + mbc), W.lv[i * 16], LH264_SYM_LUMA_DC);
     }
   } else if (lane >= 48 && lane < 56) {
     if (cdc) {
       const int i = lane - 48;
-      put_sym (out + ndc_l + i, (uint32_t) ((i * 5 + st16) * 16 + mbc), W.lv[256 + i * 16], LH264_SYM_CHROMA_DC);
+      W.osym[ndc_l + i] = mk_sym ((uint32_t) ((i * 5 + st) * 16 + mbc), W.lv[256 + i * 16], LH264_SYM_CHROMA_DC);
     }
   }
+  asm volatile ("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < total; i += 64) out[i] = W.osym[i];
   if (lane == 0) *nout = (uint16_t)total;
 }
 
