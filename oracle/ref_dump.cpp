@@ -55,10 +55,31 @@ struct Frame {
   std::vector<int16_t> levels;           // pScaledTCoeffQuant (raw levels the context model reads)
   std::vector<uint8_t> nei;              // per MB: 3 x (present, nnz[24]) for LEFT, ABOVE, PAST as the model saw them
   std::vector<std::vector<uint8_t> > syms;   // per MB: packed symbols {u8 kind, i16 value, u32 prior}
+  std::vector<int32_t> slice_extra;      // per slice: pad bit count, pad bit value, PPS transform_8x8_mode_flag, entropy_coding_mode_flag
+  std::vector<uint8_t> rtd;              // per MB: RTD_BYTES of the DecodedMacroblock the recompressor coded (have=0: skipped)
 };
 
+// what the recompressor's per-macroblock emit code reads of DecodedMacroblock (decoded_macroblock.h:12-34), packed
+enum { RTD_BYTES = 116 };
+void pack_rtd (const DecodedMacroblock& d, uint8_t* o) {
+  memset (o, 0, RTD_BYTES);
+  o[0] = 1;                                   // have
+  o[1] = d.eSliceType; o[2] = d.pTransformSize8x8Flag; o[3] = (uint8_t)d.uiCbpC; o[4] = (uint8_t)d.uiCbpL;
+  o[5] = d.uiChmaI8x8Mode; o[6] = d.uiLumaI16x16Mode; o[7] = (uint8_t)d.uiLumaQp;
+  uint32_t t = d.uiMbType; memcpy (o + 8, &t, 4);
+  uint32_t nr = d.uiNumRefIdxL0Active; memcpy (o + 12, &nr, 4);
+  int32_t sk = d.iMbSkipRun; memcpy (o + 16, &sk, 4);
+  for (int i = 0; i < 4; i++) { o[20 + i] = (uint8_t)d.iRefIdx[i]; o[24 + i] = (uint8_t)d.uiSubMbType[i]; }
+  for (int i = 0; i < 16; i++) o[28 + i] = (uint8_t) (int8_t)d.iBestIntra4x4PredMode[i];
+  memcpy (o + 44, d.sMbMvp, 64);
+  int32_t dq = (int32_t)d.cachedDeltaLumaQp; memcpy (o + 108, &dq, 4);
+  int32_t lq = d.iLastMbQp; memcpy (o + 112, &lq, 4);
+}
+
 // context-model observations collected while the reference parses a slice (before its reconstruction hook fires)
-struct MbObs { std::vector<uint8_t> syms; uint8_t nei[75]; bool have; };
+struct MbObs { std::vector<uint8_t> syms; uint8_t nei[75]; bool have; uint8_t rtd[116]; };
+const FreqImage* g_img = nullptr;
+int g_prev_mb = -1;
 std::map<int, MbObs> g_obs;     // mb index -> observation of the frame being parsed
 int g_obs_mb = -1;
 void obs_sym (int kind, int value, long prior) {
@@ -95,12 +116,14 @@ void flush_frame() {
   for (int i = 0; i < LH264_MAX_REFS; i++) put32 (i < (int)f.ref_ids.size() ? f.ref_ids[i] : -1);
   put32 (f.frame_num);
   fwrite (f.slices.data(), sizeof (lh264_slice_t), f.slices.size(), g_out);
+  fwrite (f.slice_extra.data(), 4, f.slice_extra.size(), g_out);
   fwrite (f.mbs.data(), sizeof (lh264_mb_t), f.mbs.size(), g_out);
   fwrite (f.coeffs.data(), 2, f.coeffs.size(), g_out);
   fwrite (f.covered.data(), 1, f.covered.size(), g_out);
   fwrite (f.levels.data(), 2, f.levels.size(), g_out);
   fwrite (f.nei.data(), 1, f.nei.size(), g_out);
   for (size_t k = 0; k < f.syms.size(); k++) { put32 ((int)f.syms[k].size()); fwrite (f.syms[k].data(), 1, f.syms[k].size(), g_out); }
+  fwrite (f.rtd.data(), 1, f.rtd.size(), g_out);
   for (int p = 0; p < 3; p++) fwrite (f.pre[p].data(), 1, f.pre[p].size(), g_out);
   for (int p = 0; p < 3; p++) fwrite (f.fin[p].data(), 1, f.fin[p].size(), g_out);
   g_nframes++;
@@ -137,6 +160,17 @@ void capture_final (Frame& f, int cw, int ch) {
 
 }  // namespace
 
+// The DecodedMacroblock of macroblock k is final only after its emit code ran; the reference then stores it into its
+// FreqImage (decode_slice.cpp:3101-3109), where we read it at the next hook (next macroblock, or the slice's
+// reconstruction).  A skipped macroblock's entry is a copy of PAST and is not recorded.
+void capture_prev (WelsDec::PWelsDecoderContext ctx) {
+  if (g_prev_mb < 0 || !g_img) return;
+  MbObs& o = g_obs[g_prev_mb];
+  const uint32_t t = ctx->pCurDqLayer->pMbType[g_prev_mb];
+  if (t != MB_TYPE_SKIP && t != 0) pack_rtd (g_img->at (g_prev_mb), o.rtd);
+  g_prev_mb = -1;
+}
+
 // ---- link-time hooks ------------------------------------------------------------------------
 namespace WelsDec {
 int32_t WelsTargetSliceConstruction (PWelsDecoderContext pCtx);
@@ -148,6 +182,7 @@ void __real__ZN7WelsDec25WelsDeblockingFilterSliceEPNS_21TagWelsDecoderContextEP
   PWelsDecoderContext, PDeblockingFilterMbFunc);
 
 int32_t __wrap__ZN7WelsDec27WelsTargetSliceConstructionEPNS_21TagWelsDecoderContextE (PWelsDecoderContext pCtx) {
+  capture_prev (pCtx);
   PDqLayer L = pCtx->pCurDqLayer;
   PSlice pSlice = &L->sLayerInfo.sSliceInLayer;
   PSliceHeader sh = &pSlice->sSliceHeaderExt.sSliceHeader;
@@ -167,6 +202,7 @@ int32_t __wrap__ZN7WelsDec27WelsTargetSliceConstructionEPNS_21TagWelsDecoderCont
     g_cur.covered.assign ((size_t)mbw * mbh, 0);
     g_cur.levels.assign ((size_t)mbw * mbh * 384, 0);
     g_cur.nei.assign ((size_t)mbw * mbh * 75, 0);
+    g_cur.rtd.assign ((size_t)mbw * mbh * RTD_BYTES, 0);
     g_cur.syms.assign ((size_t)mbw * mbh, std::vector<uint8_t>());
     for (int p = 0; p < 3; p++) g_cur.pre[p].assign ((size_t)mbw * mbh * (p ? 64 : 256), 0);
     g_have_cur = true;
@@ -214,6 +250,14 @@ int32_t __wrap__ZN7WelsDec27WelsTargetSliceConstructionEPNS_21TagWelsDecoderCont
   }
   const int sid = (int)f.slices.size();
   f.slices.push_back (s);
+  {   // what WelsDecodeSlice sends to the pad-byte tag after the slice's last macroblock (decode_slice.cpp:3133-3148)
+    PBitStringAux pBs = L->pBitStringAux;
+    const int nPad = 7 - (pBs->iLeftBits & 0x7);
+    f.slice_extra.push_back (nPad);
+    f.slice_extra.push_back (nPad ? (pBs->pEndBuf[-1] & ((1 << nPad) - 1)) : 0);
+    f.slice_extra.push_back (pCtx->pPps->bTransform8x8ModeFlag ? 1 : 0);
+    f.slice_extra.push_back (pCtx->pPps->bEntropyCodingModeFlag ? 1 : 0);
+  }
 
   for (int k = first; k < first + n && k < mbw * mbh; k++) {
     lh264_mb_t& m = f.mbs[k];
@@ -238,7 +282,7 @@ int32_t __wrap__ZN7WelsDec27WelsTargetSliceConstructionEPNS_21TagWelsDecoderCont
     memcpy (&f.coeffs[(size_t)k * 384], L->pScaledTCoeff[k], 768);
     memcpy (&f.levels[(size_t)k * 384], L->pScaledTCoeffQuant[k], 768);
     { std::map<int, MbObs>::iterator it = g_obs.find (k);
-      if (it != g_obs.end()) { f.syms[k] = it->second.syms; memcpy (&f.nei[(size_t)k * 75], it->second.nei, 75); g_obs.erase (it); } }
+      if (it != g_obs.end()) { f.syms[k] = it->second.syms; memcpy (&f.nei[(size_t)k * 75], it->second.nei, 75); memcpy (&f.rtd[(size_t)k * RTD_BYTES], it->second.rtd, RTD_BYTES); g_obs.erase (it); } }
     f.covered[k] = 1;
     if (m.mb_type == MB_TYPE_INTRA_PCM) {
       // the reference writes I_PCM samples into the frame while parsing (decode_slice.cpp:3213-3263);
@@ -289,10 +333,13 @@ MacroblockModel::DCPrior* REAL(MM_LDC) (MacroblockModel*, size_t);
 MacroblockModel::DCPrior* REAL(MM_CDC) (MacroblockModel*, size_t);
 
 void WRAP(MM_INIT) (MacroblockModel* self, DecodedMacroblock* mb, PWelsDecoderContext ctx, const FreqImage* f, int x, int y) {
+  capture_prev (ctx);
   REAL(MM_INIT) (self, mb, ctx, f, x, y);
   g_obs_mb = y * (int)f->width + x;
+  g_prev_mb = g_obs_mb; g_img = f;
   MbObs& o = g_obs[g_obs_mb];
   o.syms.clear();
+  memset (o.rtd, 0, sizeof (o.rtd));
   obs_nnz (self->n[Nei::LEFT], o.nei); obs_nnz (self->n[Nei::ABOVE], o.nei + 25); obs_nnz (self->n[Nei::PAST], o.nei + 50);
 }
 MacroblockModel::NonzerosPrior* WRAP(MM_NZ4) (MacroblockModel* self, int color, int idx) {
@@ -353,7 +400,7 @@ static int decode_one (const char* in, const char* outdir) {
   g_out = fopen (outp.c_str(), "wb");
   if (!g_out) { fprintf (stderr, "cannot write %s\n", outp.c_str()); return 1; }
   fwrite ("LH264DMP", 1, 8, g_out);
-  put32 (4); put32 (0);
+  put32 (5); put32 (0);
   g_nframes = 0; g_have_cur = false; g_buf_to_frame.clear(); g_obs.clear(); g_obs_mb = -1;
 
   ISVCDecoder* dec = nullptr;
@@ -368,7 +415,10 @@ static int decode_one (const char* in, const char* outdir) {
 
   long pos = 0;
   int nout = 0;
+  const char* mf = getenv ("REF_DUMP_MAX_FRAMES");       // stop feeding after this many output pictures (short fixtures)
+  const int max_out = mf ? atoi (mf) : 0;
   while (pos < sz) {
+    if (max_out > 0 && nout >= max_out) break;
     // next start-code-delimited chunk, as h264dec.cpp:246-272 does
     long i;
     for (i = 0; i < sz - pos; i++) {
@@ -388,6 +438,22 @@ static int decode_one (const char* in, const char* outdir) {
     pos += slice;
   }
   flush_frame();
+  {
+    // the recompressor's output as it would be written by the console app (h264dec.cpp:79-121): one byte string per tag
+    struct Capture : public CompressedWriter {
+      std::map<int, std::vector<uint8_t> > streams;
+      std::pair<uint32_t, H264Error> Write (int streamId, const uint8_t* data, unsigned int size) {
+        std::vector<uint8_t>& v = streams[streamId];
+        v.insert (v.end(), data, data + size);
+        return std::pair<uint32_t, H264Error> (size, 0);
+      }
+      void Close() {}
+    } cap;
+    oMovie().flushToWriter (cap);
+    fwrite ("TAGS", 1, 4, g_out);
+    put32 ((int)cap.streams.size());
+    for (auto& kv : cap.streams) { put32 (kv.first); put32 ((int)kv.second.size()); fwrite (kv.second.data(), 1, kv.second.size(), g_out); }
+  }
   fseek (g_out, 12, SEEK_SET); put32 (g_nframes);
   fclose (g_out); g_out = nullptr;
   dec->Uninitialize();

@@ -21,7 +21,7 @@ def lib():
     global _lib
     if _lib is None:
         so = os.path.join(ORACLE_DIR, "liboracle.so")
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_recon.c", "oracle_recon.h", "oracle_model.c", "oracle_model.h")]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_recon.c", "oracle_recon.h", "oracle_model.c", "oracle_model.h", "oracle_coder.c", "oracle_coder.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
         _lib = C.CDLL(so)

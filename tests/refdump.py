@@ -31,16 +31,27 @@ SYM_DTYPE = np.dtype([("kind", "u1"), ("value", "<i2"), ("prior", "<u4")])
 assert SYM_DTYPE.itemsize == 7
 
 
+# the DecodedMacroblock fields the recompressor's per-macroblock emit code reads (decoded_macroblock.h:12-34), as packed
+# by oracle/ref_dump.cpp:pack_rtd; have == 0 for skipped / uncovered macroblocks
+RTD_DTYPE = np.dtype([
+    ("have", "u1"), ("slice_type", "u1"), ("t8", "u1"), ("cbp_c", "u1"), ("cbp_l", "u1"), ("chroma_mode", "u1"),
+    ("luma16_mode", "u1"), ("luma_qp", "u1"), ("mb_type", "<u4"), ("num_ref_idx_l0", "<u4"), ("skip_run", "<i4"),
+    ("ref_idx", "i1", (4,)), ("sub_type", "u1", (4,)), ("pred_mode", "i1", (16,)), ("mvd", "<i2", (16, 2)),
+    ("delta_qp", "<i4"), ("last_mb_qp", "<i4"),
+])
+assert RTD_DTYPE.itemsize == 116
+
+
 class Frame:
     __slots__ = ("id", "mb_w", "mb_h", "crop_w", "crop_h", "has_final", "ref_ids", "slices", "mbs",
-                 "coeffs", "covered", "pre", "fin", "levels", "nei", "syms", "frame_num")
+                 "coeffs", "covered", "pre", "fin", "levels", "nei", "syms", "frame_num", "rtd", "slice_extra")
 
 
 def read_dump(path, max_frames=None):
     data = np.fromfile(path, dtype=np.uint8)
     assert bytes(data[:8]) == b"LH264DMP", "bad magic"
     ver, nfr = np.frombuffer(data[8:16].tobytes(), "<i4")
-    assert ver == 4
+    assert ver == 5
     pos = 16
     frames = []
     for _ in range(nfr if max_frames is None else min(nfr, max_frames)):
@@ -52,6 +63,8 @@ def read_dump(path, max_frames=None):
         f.frame_num = int(hdr[24])
         n = f.mb_w * f.mb_h
         f.slices = np.frombuffer(data[pos:pos + nsl * 232].tobytes(), SLICE_DTYPE).copy(); pos += nsl * 232
+        # per slice: pad bit count, pad bits, PPS transform_8x8_mode_flag, entropy_coding_mode_flag
+        f.slice_extra = np.frombuffer(data[pos:pos + nsl * 16].tobytes(), "<i4").reshape(nsl, 4).copy(); pos += nsl * 16
         f.mbs = np.frombuffer(data[pos:pos + n * 128].tobytes(), MB_DTYPE).copy(); pos += n * 128
         f.coeffs = np.frombuffer(data[pos:pos + n * 768].tobytes(), "<i2").reshape(n, 384).copy(); pos += n * 768
         f.covered = data[pos:pos + n].copy(); pos += n
@@ -61,6 +74,7 @@ def read_dump(path, max_frames=None):
         for _k in range(n):
             ln = int(np.frombuffer(data[pos:pos + 4].tobytes(), "<i4")[0]); pos += 4
             f.syms.append(np.frombuffer(data[pos:pos + ln].tobytes(), SYM_DTYPE).copy()); pos += ln
+        f.rtd = np.frombuffer(data[pos:pos + n * 116].tobytes(), RTD_DTYPE).copy(); pos += n * 116
         f.pre, f.fin = [], []
         for p in range(3):
             bs = 8 if p else 16
@@ -72,4 +86,13 @@ def read_dump(path, max_frames=None):
                 sz = n * bs * bs
                 f.fin.append(data[pos:pos + sz].reshape(f.mb_h * bs, f.mb_w * bs).copy()); pos += sz
         frames.append(f)
+    read_dump.tags = None
+    if max_frames is None and bytes(data[pos:pos + 4]) == b"TAGS":
+        pos += 4
+        nt = int(np.frombuffer(data[pos:pos + 4].tobytes(), "<i4")[0]); pos += 4
+        tags = {}
+        for _ in range(nt):
+            tag, ln = [int(x) for x in np.frombuffer(data[pos:pos + 8].tobytes(), "<i4")]; pos += 8
+            tags[tag] = bytes(data[pos:pos + ln]); pos += ln
+        read_dump.tags = tags        # the recompressor's output streams (tag 0x7fffffff = the default stream)
     return frames
