@@ -241,6 +241,20 @@ const int16_t*       lh264_parser_frame_coeffs (const lh264_parser_t* p, int idx
 const int16_t*       lh264_parser_frame_levels (const lh264_parser_t* p, int idx);
 const lh264_slice_t* lh264_parser_frame_slices (const lh264_parser_t* p, int idx);
 const uint8_t*       lh264_parser_frame_covered (const lh264_parser_t* p, int idx);
+/* row a10: the macroblock syntax the recompressor codes beyond lh264_mb_t (the reference's DecodedMacroblock fields,
+ * decoded_macroblock.h:12-34): one packed 116-byte lh264_mbsyn_t per macroblock, and per slice 4 x int32
+ * {alignment bit count after the stop bit, their value, PPS transform_8x8_mode_flag, entropy_coding_mode_flag} */
+typedef struct lh264_mbsyn {
+  uint8_t  have, slice_type, t8, cbp_c, cbp_l, chroma_mode, luma16_mode, luma_qp;
+  uint8_t  mb_type[4], num_ref_idx_l0[4], skip_run[4];   /* little-endian u32 / u32 / i32 (the struct is byte-packed) */
+  int8_t   ref_idx[4];
+  uint8_t  sub_type[4];
+  int8_t   pred_mode[16];
+  uint8_t  mvd[64];                                      /* int16 [16][2], little-endian */
+  uint8_t  delta_qp[4], last_mb_qp[4];                   /* i32 */
+} lh264_mbsyn_t;
+const lh264_mbsyn_t* lh264_parser_frame_syntax (const lh264_parser_t* p, int idx);
+const int32_t*       lh264_parser_frame_slice_syntax (const lh264_parser_t* p, int idx);
 const char*          lh264_parser_error (const lh264_parser_t* p);
 
 #define LH264_OK            0

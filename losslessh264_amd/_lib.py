@@ -70,6 +70,8 @@ _SIGS.update({
     "lh264_parser_frame_levels": (C.c_void_p, [C.c_void_p, C.c_int]),
     "lh264_parser_frame_slices": (C.c_void_p, [C.c_void_p, C.c_int]),
     "lh264_parser_frame_covered": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "lh264_parser_frame_syntax": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "lh264_parser_frame_slice_syntax": (C.c_void_p, [C.c_void_p, C.c_int]),
     "lh264_parser_error": (C.c_char_p, [C.c_void_p]),
 })
 EXPORTS = sorted(_SIGS)
@@ -105,6 +107,14 @@ def pic_geometry(mb_w, mb_h):
     return sy.value, sc.value, oy.value, ou.value, ov.value, total
 
 # ---- context-index (row a8) ----------------------------------------------------------------------------------
+# row a10 syntax record (lh264_mbsyn_t, byte-packed)
+MBSYN_DTYPE = np.dtype([
+    ("have", "u1"), ("slice_type", "u1"), ("t8", "u1"), ("cbp_c", "u1"), ("cbp_l", "u1"), ("chroma_mode", "u1"),
+    ("luma16_mode", "u1"), ("luma_qp", "u1"), ("mb_type", "<u4"), ("num_ref_idx_l0", "<u4"), ("skip_run", "<i4"),
+    ("ref_idx", "i1", (4,)), ("sub_type", "u1", (4,)), ("pred_mode", "i1", (16,)), ("mvd", "<i2", (16, 2)),
+    ("delta_qp", "<i4"), ("last_mb_qp", "<i4"),
+])
+assert MBSYN_DTYPE.itemsize == 116
 CTX_SYM_DTYPE = np.dtype([("prior", "<u4"), ("value", "<i2"), ("kind", "u1"), ("pad", "u1")])
 CTX_JOB_DTYPE = np.dtype([("mbs", "<u8"), ("levels", "<u8"), ("slices", "<u8"), ("nnz_past", "<u8"), ("nnz_cur", "<u8"),
                           ("syms", "<u8"), ("n_syms", "<u8"), ("mb_w", "<i4"), ("mb_h", "<i4")])

@@ -60,6 +60,10 @@ struct Parser::Impl {
   int prev_ref_frame_num = 0;
   bool cur_is_long = false; int cur_long_idx = -1; bool had_mmco5 = false;
   std::vector<uint8_t> rbsp;
+  // the decoder's persistent per-position arrays that the recompressor reads for every coded macroblock
+  std::vector<uint8_t> persist_chroma, persist_l16, persist_sub;
+  int persist_w = 0, persist_h = 0;
+  int slice_cached_qp = 0, slice_run_before = 0;
 
   explicit Impl (Parser* s) : self (s) {}
 
@@ -354,6 +358,11 @@ struct Parser::Impl {
     const size_t n = (size_t)S.mb_w * S.mb_h;
     cur->mbs.assign (n, lh264_mb_t()); memset (cur->mbs.data(), 0, n * sizeof (lh264_mb_t));
     cur->coeffs.assign (n * 384, 0); cur->levels.assign (n * 384, 0); cur->covered.assign (n, 0);
+    cur->syn.assign (n, MbSyn()); memset (cur->syn.data(), 0, n * sizeof (MbSyn));
+    if (persist_w != S.mb_w || persist_h != S.mb_h) {       // the decoder re-allocates (zeroed) on a resolution change
+      persist_w = S.mb_w; persist_h = S.mb_h;
+      persist_chroma.assign (n, 0); persist_l16.assign (n, 0); persist_sub.assign (n * 4, 0);
+    }
     st.assign (n, MbState());
     csps = &S; cpps = &P; first_sh = sh;
     if (sh.idr) { /* the DPB is cleared when the IDR picture is marked */ }
@@ -617,6 +626,8 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
       }
     (void)ref;
   };
+  MbSyn& y = cur->syn[k];
+  memset (&y, 0, sizeof (y));
   if (is_skip) {                                        // P_Skip: inferred motion (8.4.1.1)
     m.mb_type = LH264_MB_SKIP; s.type_class = 3;
     for (int i = 0; i < 4; i++) { s.ref[i] = 0; m.ref_idx[i] = 0; }
@@ -629,6 +640,22 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
     set_qp (qp_prev);
     return true;
   }
+  y.have = 1; y.slice_type = (uint8_t)sh.slice_type; y.num_ref_idx_l0 = (uint32_t)sh.num_ref_idx_l0;
+  y.skip_run = slice_run_before; y.last_mb_qp = qp_prev;
+  // finish the record whichever way the macroblock ends
+  struct SynDone {
+    Impl* d; MbSyn& y; lh264_mb_t& m; int k;
+    ~SynDone() {
+      y.mb_type = m.mb_type; y.t8 = (m.flags & LH264_MBF_T8x8) ? 1 : 0; y.cbp_c = m.cbp >> 4; y.cbp_l = m.cbp & 15; y.luma_qp = m.qp_y;
+      if (m.mb_type == LH264_MB_I4x4 || m.mb_type == LH264_MB_I8x8 || m.mb_type == LH264_MB_I16x16) d->persist_chroma[k] = (uint8_t)m.chroma_mode;
+      if (m.mb_type == LH264_MB_I16x16) d->persist_l16[k] = (uint8_t)m.intra_mode[0];
+      if (m.mb_type == LH264_MB_P8x8 || m.mb_type == LH264_MB_P8x8REF0) memcpy (&d->persist_sub[(size_t)k * 4], m.sub_type, 4);
+      y.chroma_mode = d->persist_chroma[k]; y.luma16_mode = d->persist_l16[k];
+      memcpy (y.sub_type, &d->persist_sub[(size_t)k * 4], 4);
+      y.delta_qp = (int)m.qp_y - d->slice_cached_qp;
+      d->slice_cached_qp = m.qp_y;
+    }
+  } syn_done = {this, y, m, k};
   uint32_t mbt = br.ue();
   bool intra = true;
   if (sh.slice_type == 0) { if (mbt < 5) intra = false; else mbt -= 5; }
@@ -672,7 +699,8 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
         int mode = pred;
         if (!br.u1()) { const int rem = (int)br.u (3); mode = rem < pred ? rem : rem + 1; }
         const int n = t8 ? 2 : 1;
-        for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) { s.ipm[(by + y) * 4 + bx + x] = (int8_t)mode; raw_modes[(by + y) * 4 + bx + x] = mode; }
+        y.pred_mode[i] = (int8_t)mode;
+        for (int yy = 0; yy < n; yy++) for (int x = 0; x < n; x++) { s.ipm[(by + yy) * 4 + bx + x] = (int8_t)mode; raw_modes[(by + yy) * 4 + bx + x] = mode; }
       }
       have_raw = true;
       chroma_mode = (int)br.ue();
@@ -703,14 +731,16 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
         for (int q = 0; q < 4; q++) if ((q >> 1) * 2 >= by && (q >> 1) * 2 < by + bh && (q & 1) * 2 >= bx && (q & 1) * 2 < bx + bw) { s.ref[q] = (int8_t)ref[i]; m.ref_idx[q] = (int8_t)ref[i]; }
         int px, py;
         predict_mv (k, sid, filled, bx, by, bw, ref[i], shape, px, py);
-        const int mvx = px + br.se(), mvy = py + br.se();
+        const int dx = br.se(), dy = br.se();
+        y.mvd[by * 4 + bx][0] = (int16_t)dx; y.mvd[by * 4 + bx][1] = (int16_t)dy; y.ref_idx[i] = (int8_t)ref[i];
+        const int mvx = px + dx, mvy = py + dy;
         fill_part (bx, by, bw, bh, ref[i], mvx, mvy, filled);
       }
     } else {
       int sub[4], ref[4] = {0, 0, 0, 0};
       for (int q = 0; q < 4; q++) { sub[q] = (int)br.ue(); if (sub[q] > 3) { fail ("invalid sub_mb_type"); return false; } m.sub_type[q] = (uint8_t) (1 << sub[q]); }
       if (mbt == 3) for (int q = 0; q < 4; q++) { ref[q] = read_ref(); if (ref[q] >= nref) { fail ("ref_idx out of range"); return false; } }
-      for (int q = 0; q < 4; q++) { s.ref[q] = (int8_t)ref[q]; m.ref_idx[q] = (int8_t)ref[q]; }
+      for (int q = 0; q < 4; q++) { s.ref[q] = (int8_t)ref[q]; m.ref_idx[q] = (int8_t)ref[q]; y.ref_idx[q] = (int8_t)ref[q]; }
       for (int q = 0; q < 4; q++) {
         const int qx = (q & 1) * 2, qy = (q >> 1) * 2;
         const int nsp = sub[q] == 0 ? 1 : sub[q] == 3 ? 4 : 2;
@@ -719,7 +749,9 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
           if (sub[q] == 1) { bh = 1; by += j; } else if (sub[q] == 2) { bw = 1; bx += j; } else if (sub[q] == 3) { bw = bh = 1; bx += j & 1; by += j >> 1; }
           int px, py;
           predict_mv (k, sid, filled, bx, by, bw, ref[q], 0, px, py);
-          const int mvx = px + br.se(), mvy = py + br.se();
+          const int dx = br.se(), dy = br.se();
+          y.mvd[by * 4 + bx][0] = (int16_t)dx; y.mvd[by * 4 + bx][1] = (int16_t)dy;
+          const int mvx = px + dx, mvy = py + dy;
           fill_part (bx, by, bw, bh, ref[q], mvx, mvy, filled);
         }
       }
@@ -812,11 +844,14 @@ bool Parser::Impl::parse_slice_data_cavlc (BitReader& br, SliceCtx& c) {
   const int n = cur->mb_w * cur->mb_h;
   int k = c.sh->first_mb, qp_prev = c.sh->slice_qp, count = 0;
   bool more = true;
+  slice_cached_qp = 0; slice_run_before = 0;
   while (more && k < n) {
+    slice_run_before = 0;
     if (c.sh->slice_type != 2) {
       uint32_t run = br.ue();
       if (br.err || (int)run > n - k) { fail ("invalid mb_skip_run"); return false; }
       for (uint32_t i = 0; i < run; i++, k++, count++) if (!parse_mb_cavlc (br, c, k, qp_prev, true)) return false;
+      slice_run_before = (int)run;
       more = br.more_rbsp_data();
       if (!more || k >= n) break;
     }
@@ -825,6 +860,16 @@ bool Parser::Impl::parse_slice_data_cavlc (BitReader& br, SliceCtx& c) {
     more = br.more_rbsp_data();
   }
   cur->slices[c.sid].n_mbs = count;
+  {   // what follows the stop bit in its byte
+    SliceSyn ss;
+    const size_t stop = br.pos;                      // position of rbsp_stop_one_bit
+    ss.pad_bits = 7 - (int) (stop & 7);
+    ss.pad_value = (ss.pad_bits && (stop >> 3) < rbsp.size()) ? (rbsp[stop >> 3] & ((1 << ss.pad_bits) - 1)) : 0;
+    ss.transform8x8_pps = c.P->transform_8x8 ? 1 : 0;
+    ss.cabac = c.P->cabac ? 1 : 0;
+    if (cur->slice_syn.size() <= (size_t)c.sid) cur->slice_syn.resize ((size_t)c.sid + 1);
+    cur->slice_syn[c.sid] = ss;
+  }
   return true;
 }
 

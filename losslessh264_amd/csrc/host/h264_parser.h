@@ -74,6 +74,30 @@ struct SliceHeader {
   int cabac_init_idc = 0, slice_qp = 26, deblock_idc = 0, alpha_off = 0, beta_off = 0;
 };
 
+// The macroblock syntax the recompressor codes beyond what lh264_mb_t carries: the fields of
+// the reference's DecodedMacroblock that its emit code reads (decoded_macroblock.h:12-34, filled by the parser and by
+// initRTDFromDecoderState decode_slice.cpp:81-109).  Several of them are whatever the decoder's persistent per-position
+// arrays hold (pChromaPredMode, pIntraPredMode[][7], pSubMbType: only written by the macroblock types that own them).
+#pragma pack(push, 1)
+struct MbSyn {
+  uint8_t have;              // 1: a coded (non-skipped) macroblock
+  uint8_t slice_type, t8, cbp_c, cbp_l;
+  uint8_t chroma_mode;       // pChromaPredMode[mb]: final chroma mode of the last intra macroblock at this position
+  uint8_t luma16_mode;       // pIntraPredMode[mb][7]: final I16x16 mode of the last I16x16 macroblock at this position
+  uint8_t luma_qp;
+  uint32_t mb_type, num_ref_idx_l0;
+  int32_t skip_run;          // length of the skip run that ended at this macroblock
+  int8_t ref_idx[4];         // as parsed, per partition
+  uint8_t sub_type[4];       // pSubMbType[mb]
+  int8_t pred_mode[16];      // Intra4x4PredMode per block in z-order (I8x8: entries 0..3)
+  int16_t mvd[16][2];        // motion vector differences as parsed, at the raster index of each partition's first block
+  int32_t delta_qp;          // luma QP minus the previous coded macroblock's (0 before the first one of a slice)
+  int32_t last_mb_qp;        // QP predictor in force when the macroblock was parsed
+};
+#pragma pack(pop)
+static_assert (sizeof (MbSyn) == 116, "MbSyn layout");
+struct SliceSyn { int32_t pad_bits, pad_value, transform8x8_pps, cabac; };   // alignment bits after the slice's stop bit (decode_slice.cpp:3133-3148)
+
 // one parsed picture: exactly what lh264_recon_chains / lh264_ctx_index_chains consume
 struct FrameOut {
   int id = 0, mb_w = 0, mb_h = 0, frame_num = 0, crop_w = 0, crop_h = 0, crop_x = 0, crop_y = 0;
@@ -85,6 +109,8 @@ struct FrameOut {
   std::vector<int> dpb_ids;             // ids still marked 'used for reference' once this picture is done (others may be freed)
   int idr_pic_id = 0, nal_ref_idc = 0;
   std::vector<uint8_t> covered;
+  std::vector<MbSyn> syn;               // per macroblock (row a10)
+  std::vector<SliceSyn> slice_syn;      // per slice
 };
 
 class Parser {

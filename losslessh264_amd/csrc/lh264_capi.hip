@@ -205,6 +205,9 @@ const int16_t* lh264_parser_frame_coeffs (const lh264_parser_t* p, int idx) { au
 const int16_t* lh264_parser_frame_levels (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? f->levels.data() : nullptr; }
 const lh264_slice_t* lh264_parser_frame_slices (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? f->slices.data() : nullptr; }
 const uint8_t* lh264_parser_frame_covered (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? f->covered.data() : nullptr; }
+static_assert (sizeof (lh264_mbsyn_t) == sizeof (lh264host::MbSyn), "lh264_mbsyn_t layout");
+const lh264_mbsyn_t* lh264_parser_frame_syntax (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? (const lh264_mbsyn_t*)f->syn.data() : nullptr; }
+const int32_t* lh264_parser_frame_slice_syntax (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? (const int32_t*)f->slice_syn.data() : nullptr; }
 const char* lh264_parser_error (const lh264_parser_t* p) { return p ? const_cast<lh264_parser_t*> (p)->p.error().c_str() : ""; }
 
 #ifdef LH264_STAMP

@@ -38,6 +38,8 @@ def parse_stream(data, strict=False):
             f.levels = arr(lib.lh264_parser_frame_levels(p, i), n * 768, "<i2").reshape(n, 384)
             f.slices = arr(lib.lh264_parser_frame_slices(p, i), ns * 232, L.SLICE_DTYPE)
             f.covered = arr(lib.lh264_parser_frame_covered(p, i), n, np.uint8)
+            f.syn = arr(lib.lh264_parser_frame_syntax(p, i), n * 116, L.MBSYN_DTYPE)
+            f.slice_syn = arr(lib.lh264_parser_frame_slice_syntax(p, i), ns * 16, "<i4").reshape(ns, 4)
             frames.append(f)
         return frames, err
     finally:

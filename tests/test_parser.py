@@ -104,3 +104,32 @@ def test_garbage_and_truncation_do_not_crash():
             b[pos] = int(rng.integers(0, 256))
         lh.parse_stream(bytes(b))
     lh.parse_stream(bytes(rng.integers(0, 256, 5000, dtype=np.uint8)))
+
+
+# ---- row a10: the syntax records the recompressor codes (lh264_mbsyn_t) against the reference's DecodedMacroblock -------
+PIP_FIXTURES = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(golden_io.GOLDEN_DIR, "pip_*.npz")))
+
+
+@pytest.mark.parametrize("name", PIP_FIXTURES)
+def test_syntax_records_match_reference(name):
+    """every field of every coded macroblock, and the per-slice alignment bits, as captured from the unmodified reference
+    (tests/golden/make_golden_pip.py)"""
+    import refdump
+    z = np.load(os.path.join(golden_io.GOLDEN_DIR, "pip_" + name + ".npz"))
+    rtd = z["rtd"].reshape(-1).view(refdump.RTD_DTYPE)
+    frames, err = lh.parse_stream(open(os.path.join(golden_io.GOLDEN_DIR, "streams", name), "rb").read())
+    assert err == ""
+    hdr = z["hdr"]
+    mb0 = s0 = 0
+    for i in range(len(hdr)):
+        n, nsl = int(hdr[i][0] * hdr[i][1]), int(hdr[i][3])
+        f = frames[i]
+        assert (f.mb_w, f.mb_h, f.frame_num) == tuple(int(x) for x in hdr[i][:3])
+        r = rtd[mb0:mb0 + n]
+        assert np.array_equal(r["have"], f.syn["have"])
+        coded = r["have"] == 1
+        for fld in refdump.RTD_DTYPE.names:
+            assert np.array_equal(r[fld][coded], f.syn[fld][coded]), (name, i, fld)
+        assert np.array_equal(z["slices"][s0:s0 + nsl, 3:6], f.slice_syn[:, :3]), (name, i)
+        mb0 += n
+        s0 += nsl
