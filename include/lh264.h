@@ -193,8 +193,22 @@ typedef struct lh264_ctx_sym {
   uint8_t  kind;      /* LH264_SYM_*                                                                   */
   uint8_t  pad;
 } lh264_ctx_sym_t;
-enum { LH264_SYM_LUMA_DC = 0, LH264_SYM_CHROMA_DC = 1, LH264_SYM_NZ4 = 2, LH264_SYM_AC4 = 3, LH264_SYM_NZ8 = 4, LH264_SYM_AC8 = 5 };
+enum { LH264_SYM_LUMA_DC = 0, LH264_SYM_CHROMA_DC = 1, LH264_SYM_NZ4 = 2, LH264_SYM_AC4 = 3, LH264_SYM_NZ8 = 4, LH264_SYM_AC8 = 5,
+       /* the non-coefficient syntax symbols (row a10), produced by the host front end; for these `prior` is
+        * LH264_PRIOR(table, index) and `pad` the tag the decisions go to (billing.h:6-55) */
+       LH264_SYM_TREE = 6,    /* value coded MSB first through a binary tree of priors (Branch<n>, compression_stream.h:117-166) */
+       LH264_SYM_POW2 = 7,    /* emitBitsZeroToPow2Inclusive<n> (:455-463): flag "differs from the preferred value" + tree      */
+       LH264_SYM_BIT = 8,     /* one decision with its own prior                                                             */
+       LH264_SYM_RAW = 9,     /* `prior` raw bits of `value`, MSB first, through the shared adaptive TEST_PROB (:441-448)      */
+       LH264_SYM_MVD = 10,    /* emitUEGkInt with MotionVectorDifferencePrior = UEGkIntPrior<9,4,3,4,3> (:575-591)            */
+       LH264_SYM_SPLICE = 15  /* marker in a host list: the macroblock's coefficient symbols (rows a8) go here             */ };
 #define LH264_CTX_MAX_SYMS 432   /* 16 + 8 + 24 + 384 symbols per macroblock at most */
+/* prior tables of the reference's MacroblockModel (macroblock_model.h:36-136) */
+enum { LH264_TB_MBTYPE = 0, LH264_TB_MVD, LH264_TB_MODE8, LH264_TB_LDC, LH264_TB_CDC, LH264_TB_NZ4, LH264_TB_NZ8, LH264_TB_AC4, LH264_TB_AC8,
+       LH264_TB_SKIPRUN, LH264_TB_QPL, LH264_TB_SUBMB, LH264_TB_NUMREF, LH264_TB_CBPC, LH264_TB_CBPL, LH264_TB_STOP, LH264_TB_T8,
+       LH264_TB_PREDMODE, LH264_TB_COUNT };
+#define LH264_PRIOR(table, index) (((uint32_t)(table) << 27) | (uint32_t)(index))
+#define LH264_MAX_SYN_SYMS 96    /* non-coefficient symbols of one macroblock at most (incl. the splice marker and a slice's pad bits) */
 
 /* One frame of context-index work.  `levels` = the raw (not dequantised) coefficient levels in the
  * pScaledTCoeffQuant layout (what the reference copies into DecodedMacroblock::odata, decode_slice.cpp:69-79).
@@ -217,6 +231,33 @@ typedef struct lh264_ctx_job {
  * later one).  Pass 1 (nnz images) runs one workgroup per chain, pass 2 (symbols) one wave per macroblock. */
 int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
                             int n_jobs, int max_mbs_per_frame, void* hip_stream);
+
+/* ---- rows a9 + a10 + f4: the adaptive binary arithmetic coder, on the device -----------------------------------
+ * Consumes, per macroblock in coding order, the host list of syntax symbols (with the SPLICE marker where the
+ * coefficient symbols of lh264_ctx_index_chains go) and produces the byte string of every tagged stream exactly as
+ * the reference's compressor writes it to <out>.pip.<tag> (ArithmeticCodedOutput / vpx_writer,
+ * compression_stream.h:353-487, bitwriter.h:35-105; DynProb :87-115; emitInt / emitUEGkInt :523-591).
+ * One workgroup (one wave) per stream; lane t holds the bool-coder state of tag slot t.  The adaptive priors live in
+ * a per-stream open-addressing hash table in HBM (a cell = 16 packed DynProbs = 64 bytes), zero-filled by the caller. */
+#define LH264_N_TAG_SLOTS 40
+typedef struct lh264_code_job {
+  const lh264_ctx_sym_t* syn_syms_dev;   /* host symbols of the picture, macroblock after macroblock        */
+  const uint32_t*        syn_off_dev;    /* n_mbs + 1 offsets into syn_syms_dev                             */
+  const lh264_ctx_sym_t* ctx_syms_dev;   /* n_mbs * LH264_CTX_MAX_SYMS (lh264_ctx_job_t.syms_dev)           */
+  const uint16_t*        ctx_n_syms_dev; /* n_mbs                                                           */
+  int32_t n_mbs, reserved;
+} lh264_code_job_t;
+typedef struct lh264_code_stream {
+  uint32_t* hash_keys_dev;     /* hash_cap entries, zero-filled                                             */
+  uint32_t* hash_cells_dev;    /* hash_cap * 16, zero-filled                                                */
+  uint8_t*  out_dev;           /* LH264_N_TAG_SLOTS * out_cap bytes: slot t at t * out_cap                  */
+  uint32_t* out_len_dev;       /* LH264_N_TAG_SLOTS lengths (0: tag never used); [LH264_N_TAG_SLOTS] = status (0 ok) */
+  uint32_t  hash_cap;          /* power of two                                                              */
+  uint32_t  out_cap;
+} lh264_code_stream_t;
+/* tag id (billing.h) <-> slot: slot = tag for tags < 34, slot 34 = tag 69 (pad bits) */
+int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
+                       int n_chains, void* hip_stream);
 
 /* ---- host front end: Annex-B bitstream -> macroblock records ------------------------------
  * Replaces, for the records the hot path needs, the reference's WelsDecodeBs / ParseNonVclNal / slice-header parse /
@@ -255,6 +296,9 @@ typedef struct lh264_mbsyn {
 } lh264_mbsyn_t;
 const lh264_mbsyn_t* lh264_parser_frame_syntax (const lh264_parser_t* p, int idx);
 const int32_t*       lh264_parser_frame_slice_syntax (const lh264_parser_t* p, int idx);
+/* the row-a10 symbols of the picture (LH264_SYM_TREE .. LH264_SYM_SPLICE) and mb_w*mb_h + 1 offsets into them */
+const lh264_ctx_sym_t* lh264_parser_frame_syn_symbols (const lh264_parser_t* p, int idx, int* count);
+const uint32_t*      lh264_parser_frame_syn_offsets (const lh264_parser_t* p, int idx);
 const char*          lh264_parser_error (const lh264_parser_t* p);
 
 #define LH264_OK            0

@@ -72,6 +72,8 @@ _SIGS.update({
     "lh264_parser_frame_covered": (C.c_void_p, [C.c_void_p, C.c_int]),
     "lh264_parser_frame_syntax": (C.c_void_p, [C.c_void_p, C.c_int]),
     "lh264_parser_frame_slice_syntax": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "lh264_parser_frame_syn_symbols": (C.c_void_p, [C.c_void_p, C.c_int, C.c_void_p]),
+    "lh264_parser_frame_syn_offsets": (C.c_void_p, [C.c_void_p, C.c_int]),
     "lh264_parser_error": (C.c_char_p, [C.c_void_p]),
 })
 EXPORTS = sorted(_SIGS)

@@ -2,6 +2,7 @@
 // (intra mode and motion vector prediction), 9.2 (CAVLC).  Frame (progressive) pictures, I and P slices, one slice
 // group -- the subset the reference decoder itself supports.
 #include "h264_parser.h"
+#include "pip_symbols.h"
 #include <string.h>
 #include <algorithm>
 #include "h264_tables.h"
@@ -64,6 +65,7 @@ struct Parser::Impl {
   std::vector<uint8_t> persist_chroma, persist_l16, persist_sub;
   int persist_w = 0, persist_h = 0;
   int slice_cached_qp = 0, slice_run_before = 0;
+  Symbolizer symbolizer;
 
   explicit Impl (Parser* s) : self (s) {}
 
@@ -342,6 +344,7 @@ struct Parser::Impl {
     if (first_sh.nal_ref_idc) { mark_reference (first_sh, *csps); cur->is_ref = true; prev_ref_frame_num = had_mmco5 ? 0 : first_sh.frame_num; }
     had_mmco5 = false;
     for (const auto& d : dpb) cur->dpb_ids.push_back (d.frame_id);
+    if (cur->slice_syn.size() == cur->slices.size()) symbolizer.picture (*cur);
     cur->complete = true;
     self->frames_.push_back (std::move (cur));
     cur.reset();

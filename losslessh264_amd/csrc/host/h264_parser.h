@@ -111,6 +111,8 @@ struct FrameOut {
   std::vector<uint8_t> covered;
   std::vector<MbSyn> syn;               // per macroblock (row a10)
   std::vector<SliceSyn> slice_syn;      // per slice
+  std::vector<lh264_ctx_sym_t> syn_syms;   // the picture's row-a10 symbols (Symbolizer), macroblock after macroblock
+  std::vector<uint32_t> syn_off;           // mb_w*mb_h + 1 offsets
 };
 
 class Parser {

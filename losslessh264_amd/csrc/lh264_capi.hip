@@ -208,6 +208,12 @@ const uint8_t* lh264_parser_frame_covered (const lh264_parser_t* p, int idx) { a
 static_assert (sizeof (lh264_mbsyn_t) == sizeof (lh264host::MbSyn), "lh264_mbsyn_t layout");
 const lh264_mbsyn_t* lh264_parser_frame_syntax (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? (const lh264_mbsyn_t*)f->syn.data() : nullptr; }
 const int32_t* lh264_parser_frame_slice_syntax (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? (const int32_t*)f->slice_syn.data() : nullptr; }
+const lh264_ctx_sym_t* lh264_parser_frame_syn_symbols (const lh264_parser_t* p, int idx, int* count) {
+  auto f = pf (p, idx);
+  if (count) *count = f ? (int)f->syn_syms.size() : 0;
+  return f ? f->syn_syms.data() : nullptr;
+}
+const uint32_t* lh264_parser_frame_syn_offsets (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? f->syn_off.data() : nullptr; }
 const char* lh264_parser_error (const lh264_parser_t* p) { return p ? const_cast<lh264_parser_t*> (p)->p.error().c_str() : ""; }
 
 #ifdef LH264_STAMP

@@ -40,6 +40,10 @@ def parse_stream(data, strict=False):
             f.covered = arr(lib.lh264_parser_frame_covered(p, i), n, np.uint8)
             f.syn = arr(lib.lh264_parser_frame_syntax(p, i), n * 116, L.MBSYN_DTYPE)
             f.slice_syn = arr(lib.lh264_parser_frame_slice_syntax(p, i), ns * 16, "<i4").reshape(ns, 4)
+            cnt = C.c_int(0)
+            ptr = lib.lh264_parser_frame_syn_symbols(p, i, C.byref(cnt))
+            f.syn_syms = arr(ptr, cnt.value * 8, L.CTX_SYM_DTYPE) if cnt.value else np.zeros(0, L.CTX_SYM_DTYPE)
+            f.syn_off = arr(lib.lh264_parser_frame_syn_offsets(p, i), (n + 1) * 4, "<u4")
             frames.append(f)
         return frames, err
     finally:

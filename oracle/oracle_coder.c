@@ -479,6 +479,48 @@ int orc_coder_picture (orc_coder_t* c, int mb_w, int mb_h, int frame_num, const 
   return 0;
 }
 
+/* Code a flat list of symbols in the product's record format (include/lh264.h: lh264_ctx_sym_t with the LH264_SYM_* kinds
+ * 0..10; SPLICE markers must have been resolved by the caller).  The checker of the product's host symbolizer. */
+int orc_coder_symbols (orc_coder_t* c, const orc_sym_t* syms, long n) {
+  static const int tree_bits[TB_COUNT] = { 4, 0, 3, 0, 0, 0, 0, 0, 0, 9, 7, 8, 4, 2, 4, 0, 0, 4 };
+  for (long i = 0; i < n; i++) {
+    const orc_sym_t* sy = &syms[i];
+    const int table = (int) (sy->prior >> 27);
+    const uint32_t index = sy->prior & 0x7ffffffu;
+    const int tag = sy->pad;
+    switch (sy->kind) {
+    case ORC_SYM_LUMA_DC: case ORC_SYM_CHROMA_DC: {
+      dynprob_t* cell = store_get (&c->st, sy->kind == ORC_SYM_LUMA_DC ? TB_LDC : TB_CDC, sy->prior);
+      intprior_t p; p.exponent = cell; p.E = 3; p.mantissa = cell + 3; p.M = 4; p.zero = cell + 7; p.sign = cell + 8; p.order = 0;
+      const int t = sy->kind == ORC_SYM_LUMA_DC ? T_LDC : T_CRDC;
+      emit_int (c, sy->value, &p, t, t, t, t);
+      break; }
+    case ORC_SYM_NZ4: case ORC_SYM_NZ8: {
+      dynprob_t* cell = store_get (&c->st, sy->kind == ORC_SYM_NZ4 ? TB_NZ4 : TB_NZ8, sy->prior);
+      intprior_t p; p.exponent = cell; p.E = 3; p.mantissa = cell + 3; p.M = 4; p.zero = cell + 7; p.sign = NULL; p.order = 0;
+      const int t = ((sy->prior / 27) % 3) ? T_CRAC_EOB : T_LAC_0_EOB;
+      emit_int (c, sy->value, &p, t, t, t, t);
+      break; }
+    case ORC_SYM_AC4: case ORC_SYM_AC8: {
+      const int nco = sy->kind == ORC_SYM_AC4 ? 16 : 64;
+      const uint32_t outer = sy->prior / 3125;
+      const int emitted = (int) (outer % nco), color = (int) ((outer / nco) % 3), code = (int) ((outer / nco / 3) % 16);
+      const int first = color == 0 && emitted == 0 && code != 1;
+      const int base = color ? T_CRAC_EOB : (first ? T_LAC_0_EOB : T_LAC_N_EOB);
+      if (!c->w[base + 2].used) w_start (&c->w[base + 2]);
+      emit_uegk (c, sy->value, store_get (&c->st, sy->kind == ORC_SYM_AC4 ? TB_AC4 : TB_AC8, sy->prior), 14, 4, 2, 4, 0, base + 2, base + 3, base + 1, base + 4);
+      break; }
+    case 6: /* TREE */ emit_tree (c, tag, (unsigned) (uint16_t)sy->value, tree_bits[table], store_get (&c->st, table, index)); break;
+    case 7: /* POW2 */ emit_pow2 (c, tag, (unsigned) (uint16_t)sy->value, tree_bits[table], store_get (&c->st, table, index), table == TB_MODE8 ? index : 0); break;
+    case 8: /* BIT */ emit_bit (c, tag, sy->value != 0, store_get (&c->st, table, index)); break;
+    case 9: /* RAW */ emit_raw_bits (c, tag, (unsigned) (uint16_t)sy->value, (int)sy->prior); break;
+    case 10: /* MVD */ emit_uegk (c, sy->value, store_get (&c->st, TB_MVD, index), 9, 4, 3, 4, 3, tag, tag, tag, tag); break;
+    default: snprintf (c->err, sizeof (c->err), "symbol %ld: unknown kind %d", i, sy->kind); return -1;
+    }
+  }
+  return 0;
+}
+
 void orc_coder_finish (orc_coder_t* c) {
   for (int t = 0; t < N_TAGS; t++) if (c->w[t].used) w_stop (&c->w[t]);
 }

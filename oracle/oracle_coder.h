@@ -44,6 +44,9 @@ void orc_coder_free (orc_coder_t* c);
  * neighbour availability bits of intra NxN macroblocks (lh264_mb_t.intra_avail: T 1, TL 2, L 4) */
 int orc_coder_picture (orc_coder_t* c, int mb_w, int mb_h, int frame_num, const uint16_t* mb_types, const int16_t* levels,
                        const orc_rtd_t* rtd, const uint8_t* avail, const orc_slice_info_t* slices, int n_slices);
+/* code a flat list of symbols given in the product's record format (include/lh264.h lh264_ctx_sym_t, LH264_SYM_* kinds 0..10) */
+struct orc_sym;
+int orc_coder_symbols (orc_coder_t* c, const struct orc_sym* syms, long n);
 /* vpx_stop_encode on every tag; afterwards orc_coder_tag returns the final bytes */
 void orc_coder_finish (orc_coder_t* c);
 int orc_coder_tag (orc_coder_t* c, int tag, const uint8_t** bytes);     /* length, 0 if the tag was never used */

@@ -73,3 +73,45 @@ def test_tag_streams_equal_reference(name):
 
 def test_fixtures_present():
     assert len(FIXTURES) >= 5
+
+
+# ---- the product's host symbolizer (losslessh264_amd/csrc/host/pip_symbols.cpp), checked on the CPU -------------------
+def _merged_symbols(name, z):
+    """host symbols of the parser + the oracle's coefficient symbols at the splice markers, as one flat array"""
+    import losslessh264_amd as lh
+    from losslessh264_amd.ctx import past_policy
+    frames, err = lh.parse_stream(open(os.path.join(GOLDEN, "streams", name), "rb").read())
+    assert err == ""
+    frames = frames[:len(z["hdr"])]
+    pol = past_policy(frames)
+    imgs = O.model_nnz_images(frames, pol)
+    out = []
+    for i, f in enumerate(frames):
+        ctx = O.model_frame_symbols(f, imgs[i], imgs[pol[i]] if pol[i] is not None else None)
+        for k in range(f.mb_w * f.mb_h):
+            hs = f.syn_syms[f.syn_off[k]:f.syn_off[k + 1]]
+            for s in hs:
+                if s["kind"] == 15:
+                    out.append(ctx[k])
+                else:
+                    out.append(np.array([s], dtype=O.ORC_SYM_DTYPE))
+    return np.ascontiguousarray(np.concatenate(out))
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_host_symbolizer_yields_reference_bytes(name):
+    z = load_pip(name)
+    syms = _merged_symbols(name, z)
+    L = O.lib()
+    L.orc_coder_new.restype = C.c_void_p
+    L.orc_coder_error.restype = C.c_char_p
+    c = C.c_void_p(L.orc_coder_new(0))
+    assert L.orc_coder_symbols(c, syms.ctypes.data_as(C.c_void_p), C.c_long(len(syms))) == 0, L.orc_coder_error(c)
+    L.orc_coder_finish(c)
+    ref = {int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")}
+    for t in sorted(ref):
+        p = C.c_void_p()
+        ln = L.orc_coder_tag(c, t, C.byref(p))
+        got = bytes(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(ln,))) if ln else b""
+        assert got == ref[t], "tag %d: %d bytes, reference %d" % (t, len(got), len(ref[t]))
+    L.orc_coder_free(c)
