@@ -9,5 +9,6 @@ from ._lib import lib, LibraryMissing, MB_DTYPE, SLICE_DTYPE, JOB_DTYPE, pic_geo
 from .recon import ReconSession  # noqa: F401
 from .ctx import CtxSession, past_policy  # noqa: F401
 from .parse import parse_stream  # noqa: F401
+from .coder import CoderSession  # noqa: F401
 
-__all__ = ["lib", "LibraryMissing", "ReconSession", "CtxSession", "past_policy", "parse_stream", "MB_DTYPE", "SLICE_DTYPE", "JOB_DTYPE", "pic_geometry"]
+__all__ = ["lib", "LibraryMissing", "ReconSession", "CtxSession", "past_policy", "parse_stream", "CoderSession", "MB_DTYPE", "SLICE_DTYPE", "JOB_DTYPE", "pic_geometry"]

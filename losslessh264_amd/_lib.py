@@ -76,6 +76,11 @@ _SIGS.update({
     "lh264_parser_frame_syn_offsets": (C.c_void_p, [C.c_void_p, C.c_int]),
     "lh264_parser_error": (C.c_char_p, [C.c_void_p]),
 })
+CODE_JOB_DTYPE = np.dtype([("syn_syms", "<u8"), ("syn_off", "<u8"), ("ctx_syms", "<u8"), ("ctx_n_syms", "<u8"), ("n_mbs", "<i4"), ("reserved", "<i4")])
+CODE_STREAM_DTYPE = np.dtype([("hash_keys", "<u8"), ("hash_cells", "<u8"), ("out", "<u8"), ("out_len", "<u8"), ("hash_cap", "<u4"), ("out_cap", "<u4")])
+N_TAG_SLOTS = 40
+assert CODE_JOB_DTYPE.itemsize == 40 and CODE_STREAM_DTYPE.itemsize == 40
+_SIGS["lh264_code_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
 EXPORTS = sorted(_SIGS)
 
 
@@ -123,4 +128,9 @@ CTX_JOB_DTYPE = np.dtype([("mbs", "<u8"), ("levels", "<u8"), ("slices", "<u8"), 
 CTX_MAX_SYMS = 432
 assert CTX_SYM_DTYPE.itemsize == 8 and CTX_JOB_DTYPE.itemsize == 64
 _SIGS["lh264_ctx_index_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p])
+CODE_JOB_DTYPE = np.dtype([("syn_syms", "<u8"), ("syn_off", "<u8"), ("ctx_syms", "<u8"), ("ctx_n_syms", "<u8"), ("n_mbs", "<i4"), ("reserved", "<i4")])
+CODE_STREAM_DTYPE = np.dtype([("hash_keys", "<u8"), ("hash_cells", "<u8"), ("out", "<u8"), ("out_len", "<u8"), ("hash_cap", "<u4"), ("out_cap", "<u4")])
+N_TAG_SLOTS = 40
+assert CODE_JOB_DTYPE.itemsize == 40 and CODE_STREAM_DTYPE.itemsize == 40
+_SIGS["lh264_code_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
 EXPORTS = sorted(_SIGS)

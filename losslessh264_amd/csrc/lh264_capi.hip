@@ -14,6 +14,7 @@ __global__ void recon_chain_kernel (const lh264_frame_job_t* jobs, const int32_t
 __global__ void ctx_nnz_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
 __global__ void ctx_inherit_chain_kernel (const lh264_ctx_job_t* jobs, const int32_t* chain_first, int n_chains);
 __global__ void ctx_symbols_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
+__global__ void coder_chain_kernel (const lh264_code_job_t* jobs, const int32_t* chain_first, const lh264_code_stream_t* streams, int n_chains);
 size_t wave_lds_bytes();
 size_t wg_lds_bytes();
 #ifdef LH264_STAMP
@@ -154,6 +155,16 @@ int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chai
   hipLaunchKernelGGL (lh264::ctx_inherit_chain_kernel, dim3 (n_chains), dim3 (256), 0, st, jobs_dev, chain_first_dev, n_chains);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::ctx_symbols_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, n_jobs, bpj);
+  HIPCHK (hipGetLastError());
+  return LH264_OK;
+}
+
+int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
+                       int n_chains, void* stream) {
+  if (lh264_device_count() <= 0) return fail (LH264_E_NODEVICE, "no HIP device visible");
+  if (!jobs_dev || !chain_first_dev || !streams_dev || n_chains < 0) return fail (LH264_E_ARG, "bad argument");
+  if (n_chains == 0) return LH264_OK;
+  hipLaunchKernelGGL (lh264::coder_chain_kernel, dim3 (n_chains), dim3 (64), 0, (hipStream_t)stream, jobs_dev, chain_first_dev, streams_dev, n_chains);
   HIPCHK (hipGetLastError());
   return LH264_OK;
 }

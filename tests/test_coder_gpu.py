@@ -1,0 +1,53 @@
+"""Rows a9/a10/f4 on the device: product path .264 -> host front end (records + syntax symbols) -> HIP context-index
+kernels (coefficient symbols) -> HIP coder.  Every tagged arithmetic-coded stream must equal, byte for byte, what the
+reference's compressor wrote for the same stream (tests/golden/pip_*.npz, generated from the unmodified reference)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+FIXTURES = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(golden_io.GOLDEN_DIR, "pip_*.npz")))
+
+
+def _frames(name, z):
+    import losslessh264_amd as lh
+    frames, err = lh.parse_stream(open(os.path.join(golden_io.GOLDEN_DIR, "streams", name), "rb").read())
+    assert err == ""
+    return frames[:len(z["hdr"])]
+
+
+def test_device_coder_equals_reference_bytes():
+    import losslessh264_amd as lh
+    streams, refs = [], []
+    for name in FIXTURES:
+        z = np.load(os.path.join(golden_io.GOLDEN_DIR, "pip_" + name + ".npz"))
+        streams.append(_frames(name, z))
+        refs.append({int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")})
+    ctx = lh.CtxSession(streams)
+    ctx.run()
+    coder = lh.CoderSession(ctx, out_cap=1 << 17)
+    coder.run()
+    ctx.synchronize()
+    for c, name in enumerate(FIXTURES):
+        got = coder.tags(c)
+        assert sorted(got) == sorted(refs[c]), (name, sorted(got), sorted(refs[c]))
+        for t in sorted(refs[c]):
+            assert got[t] == refs[c][t], "%s tag %d: %d bytes, reference %d" % (name, t, len(got[t]), len(refs[c][t]))
+
+
+def test_replicas_are_identical_and_rerun_is_stable():
+    import losslessh264_amd as lh
+    name = "SVA_BA2_D.264"
+    z = np.load(os.path.join(golden_io.GOLDEN_DIR, "pip_" + name + ".npz"))
+    ctx = lh.CtxSession([_frames(name, z)], replicate=5)
+    ctx.run()
+    coder = lh.CoderSession(ctx)
+    coder.run(); coder.run()
+    ctx.synchronize()
+    ref = {int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")}
+    for c in range(5):
+        assert coder.tags(c) == ref
