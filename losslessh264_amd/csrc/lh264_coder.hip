@@ -20,6 +20,7 @@
 namespace lh264 {
 
 #define GLB __attribute__ ((address_space (1)))
+typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
 template <typename T> __device__ __forceinline__ GLB T* glb (const void* p) { return (GLB T*) (uintptr_t)p; }
 __device__ __forceinline__ int uniform (int v) { return __builtin_amdgcn_readfirstlane (v); }
 
@@ -28,7 +29,12 @@ __device__ __forceinline__ int dp_prob (uint32_t s) { return (int) (((s >> 20) +
 __device__ __forceinline__ uint32_t dp_update (uint32_t s, int bit) {
   uint32_t c0 = s & 1023u, c1 = (s >> 10) & 1023u;
   if (bit) c1++; else c0++;
-  const uint32_t prob = (256u * (c0 + 1u)) / (c0 + c1 + 2u);
+  // floor (256 (c0+1) / (c0+c1+2)) < 256: numerator < 2^18,
+  // divisor <= 516: a float quotient is within one of the exact one
+  const uint32_t num = 256u * (c0 + 1u), den = c0 + c1 + 2u;
+  uint32_t prob = (uint32_t) ((float)num * __frcp_rn ((float)den));
+  if (prob * den > num) prob--;
+  else if ((prob + 1u) * den <= num) prob++;
   if (c0 + c1 > 512u) { c0 = (c0 + 1u) >> 1; c1 = (c1 + 1u) >> 1; }
   return c0 | (c1 << 10) | (((prob + 128u) & 255u) << 20);
 }
@@ -105,6 +111,9 @@ __device__ __forceinline__ void cell_flush (Coder& c) {
 }
 // make the cell of `key` the one in hand (find or insert)
 __device__ __forceinline__ void cell_get (Coder& c, uint32_t key) {
+#ifdef LH264_CODER_ABL_NOMEM
+  key &= 63u;               // timing ablation: (nearly) always the cell in hand or an L1 hit
+#endif
   if (c.have_cell && c.cur_key == key) return;
   cell_flush (c);
   uint32_t h = (key * 0x9E3779B1u) >> 7;
@@ -125,135 +134,229 @@ __device__ __forceinline__ void cell_get (Coder& c, uint32_t key) {
   c.cur_key = key; c.cur_slot = 0; c.have_cell = false; c.cellv = 0;
 }
 
-// one decision with DynProb j of the cell in hand, coded into tag `tag`
-__device__ __forceinline__ void decide (Coder& c, int j, int bit, int tag) {
-  const uint32_t s = (uint32_t)__builtin_amdgcn_readlane ((int)c.cellv, j);
-  const int prob = dp_prob (s);
-  const uint32_t ns = dp_update (s, bit);
-  if (c.lane == j) c.cellv = ns;
-  const int slot = tag_slot (tag);
-  if (c.lane == slot) bc_write (c.bc, c.out + (size_t)slot * c.cap, c.cap, bit, prob);
-}
-__device__ __forceinline__ void decide_raw (Coder& c, int bit, int tag) {        // emitBit(bit): the shared TEST_PROB
-  const int prob = dp_prob (c.test_prob);
-  c.test_prob = dp_update (c.test_prob, bit);
-  const int slot = tag_slot (tag);
-  if (c.lane == slot) bc_write (c.bc, c.out + (size_t)slot * c.cap, c.cap, bit, prob);
-}
 __device__ __forceinline__ void touch_tag (Coder& c, int tag) {       // a stream exists once tag() was called for it
   const int slot = tag_slot (tag);
   if (c.lane == slot && !c.bc.used) { c.bc.low = 0; c.bc.range = 255; c.bc.count = -24; c.bc.pos = 0; c.bc.ffrun = 0; c.bc.pending = -1; c.bc.used = 1; c.bc.last = 0; }
 }
 
+// ---- binarisation: a symbol becomes a short list of decisions ---------------------------------------------------------------
+// Done by 64 lanes at once, one symbol per lane, into the lane's row of an LDS table.  A decision is one word: bits 0..7
+// the place of its DynProb in the cell in hand (0xff: a raw bit, coded with TEST_PROB), bit 8 the bit, bits 16..23 the tag.
+// A word with bit 31 set switches cells: the next word is the key (+1) of the cell the following decisions use (priors
+// that are trees of more than 16 nodes span several cells).
+#define DL_STRIDE 56
+struct DList { uint32_t* row; int n; };            // row: LDS
+__device__ __forceinline__ void push (DList& d, int j, int bit, int tag) {
+  if (d.n < DL_STRIDE) d.row[d.n] = (uint32_t) (j & 0xff) | ((uint32_t) (bit & 1) << 8) | ((uint32_t)tag << 16);
+  d.n++;
+}
+__device__ __forceinline__ void push_switch (DList& d, uint32_t key) {
+  if (d.n + 1 < DL_STRIDE) { d.row[d.n] = 0x80000000u; d.row[d.n + 1] = key + 1u; }
+  d.n += 2;
+}
 // UnaryIntPrior<n>::at(i) = prior[min(i, n-1)]; emitUnary compression_stream.h:465-474
-__device__ __forceinline__ void emit_unary (Coder& c, int data, int base, int n, int early, int tag) {
+__device__ __forceinline__ void b_unary (DList& d, int data, int base, int n, int early, int tag) {
   for (int i = 0; i < data; i++) {
-    decide (c, base + (i < n - 1 ? i : n - 1), 1, tag);
+    push (d, base + (i < n - 1 ? i : n - 1), 1, tag);
     if (i == early - 1) return;
   }
-  decide (c, base + (data < n - 1 ? data : n - 1), 0, tag);
+  push (d, base + (data < n - 1 ? data : n - 1), 0, tag);
 }
 // emitInt :523-572 with the prior's parts at fixed places of the cell (zero / sign < 0: the prior has none)
-__device__ __forceinline__ void emit_int (Coder& c, int data, int zero, int sign, int ebase, int E, int mbase, int M, int order,
-                                          int tag_exp, int tag_man, int tag_zero, int tag_sign) {
-  if (zero >= 0) { decide (c, zero, data == 0, tag_zero); if (data == 0) return; }
-  if (sign >= 0) { decide (c, sign, data > 0, tag_sign); if (data < 0) data = -data; }
+__device__ __forceinline__ void b_int (DList& d, int data, int zero, int sign, int ebase, int E, int mbase, int M, int order,
+                                       int tag_exp, int tag_man, int tag_zero, int tag_sign) {
+  if (zero >= 0) { push (d, zero, data == 0, tag_zero); if (data == 0) return; }
+  if (sign >= 0) { push (d, sign, data > 0, tag_sign); if (data < 0) data = -data; }
   data--;
-  int log2 = 0;
   const int data_high = 1 + (data >> order);
-  while ((2 << log2) <= data_high) log2++;
-  emit_unary (c, log2, ebase, E, -1, tag_exp);
+  const int log2 = 31 - __clz (data_high);               // largest l with (1 << l) <= data_high
+  b_unary (d, log2, ebase, E, -1, tag_exp);
   int lo = 0, hi = M;
   const int nb = log2 + order;
   for (int i = 0; i < nb; i++) {
     const int bit = i < log2 ? (data_high >> (log2 - 1 - i)) & 1 : (data >> (order - 1 - (i - log2))) & 1;
     if (hi > lo) {
       const int mid = (hi + lo) / 2;
-      decide (c, mbase + mid, bit, tag_man);
+      push (d, mbase + mid, bit, tag_man);
       if (bit) lo = mid + 1; else hi = mid;
-    } else decide_raw (c, bit, tag_man);
+    } else push (d, 0xff, bit, tag_man);
   }
 }
 // emitUEGkInt :575-591; cell: zero 0, sign 1, first 2..2+M-1, second = {zero, exponent[E], mantissa[Mant]}
-__device__ __forceinline__ void emit_uegk (Coder& c, int data, int N, int M, int E, int Mant, int order, int tag_exp, int tag_man, int tag_zero, int tag_sign) {
-  decide (c, 0, data == 0, tag_zero);
+__device__ __forceinline__ void b_uegk (DList& d, int data, int N, int M, int E, int Mant, int order, int tag_exp, int tag_man, int tag_zero, int tag_sign) {
+  push (d, 0, data == 0, tag_zero);
   if (data == 0) return;
-  decide (c, 1, data < 0, tag_sign);
+  push (d, 1, data < 0, tag_sign);
   if (data < 0) data = -data;
-  emit_unary (c, data - 1, 2, M, N, tag_man);
-  if (data - 1 >= N) emit_int (c, data - 1 - N, 2 + M, -1, 2 + M + 1, E, 2 + M + 1 + E, Mant, order, tag_exp, tag_man, tag_zero, tag_sign);
+  b_unary (d, data - 1, 2, M, N, tag_man);
+  if (data - 1 >= N) b_int (d, data - 1 - N, 2 + M, -1, 2 + M + 1, E, 2 + M + 1 + E, Mant, order, tag_exp, tag_man, tag_zero, tag_sign);
 }
-// Branch<nbits> (:117-166): a node's array = itself, its 0-subtree, its 1-subtree.  Tables with more than 16 nodes span several
-// cells: node n lives in cell (index * groups + n / 16), place n % 16.
-__device__ __forceinline__ void emit_tree (Coder& c, uint32_t base_key, int groups, int first_node, unsigned data, int nbits, int tag) {
-  unsigned off = (unsigned)first_node;
+// Branch<nbits> (:117-166): a node's array = itself, its 0-subtree, its 1-subtree.  With more than 16 nodes, node n lives
+// in cell index * groups + n / 16, place n % 16.
+__device__ __forceinline__ void b_tree (DList& d, uint32_t prior, int groups, unsigned off, unsigned data, int nbits, int tag, int cur_group) {
+  const uint32_t index = prior & 0x7ffffffu;
   for (int n = nbits; n >= 1; n--) {
     const int bit = (data >> (n - 1)) & 1;
-    if (groups > 1) cell_get (c, (base_key & 0xf8000000u) | ((base_key & 0x7ffffffu) * (uint32_t)groups + (off >> 4)));
-    decide (c, (int) (off & 15u), bit, tag);
-    const unsigned children = (1u << (n - 1)) - 1u;
-    off += bit ? 1u + children : 1u;
+    if (groups > 1 && (int) (off >> 4) != cur_group) { cur_group = (int) (off >> 4); push_switch (d, (prior & 0xf8000000u) | (index * (uint32_t)groups + (off >> 4))); }
+    push (d, (int) (off & 15u), bit, tag);
+    off += bit ? 1u + ((1u << (n - 1)) - 1u) : 1u;
   }
 }
 
-__device__ __forceinline__ void code_symbol (Coder& c, uint32_t prior, int value, int kind, int pad) {
+// one symbol -> its decision list; returns the key (+1) of its cell when it uses exactly one (0: none or switches inside);
+// touch: the tag the symbol brings into existence (or -1)
+__device__ __forceinline__ uint32_t build_symbol (DList& d, uint32_t prior, int value, int kind, int pad, int& touch) {
+  enum { T_LDC = 17, T_CRDC = 18, T_LAC_0_EOB = 19, T_LAC_N_EOB = 24, T_CRAC_EOB = 29 };
   const int table = (int) (prior >> 27);
   const uint32_t index = prior & 0x7ffffffu;
-  enum { T_LDC = 17, T_CRDC = 18, T_LAC_0_EOB = 19, T_LAC_N_EOB = 24, T_CRAC_EOB = 29 };
+  touch = -1;
   switch (kind) {
   case LH264_SYM_LUMA_DC: case LH264_SYM_CHROMA_DC: {      // IntPrior<3,4>: exponent 0..2, mantissa 3..6, zero 7, sign 8
-    cell_get (c, LH264_PRIOR (kind == LH264_SYM_LUMA_DC ? LH264_TB_LDC : LH264_TB_CDC, prior));
     const int t = kind == LH264_SYM_LUMA_DC ? T_LDC : T_CRDC;
-    emit_int (c, value, 7, 8, 0, 3, 3, 4, 0, t, t, t, t);
-    break; }
+    b_int (d, value, 7, 8, 0, 3, 3, 4, 0, t, t, t, t);
+    return LH264_PRIOR (kind == LH264_SYM_LUMA_DC ? LH264_TB_LDC : LH264_TB_CDC, prior) + 1u; }
   case LH264_SYM_NZ4: case LH264_SYM_NZ8: {                 // UnsignedIntPrior<3,4>
-    cell_get (c, LH264_PRIOR (kind == LH264_SYM_NZ4 ? LH264_TB_NZ4 : LH264_TB_NZ8, prior));
     const int t = ((prior / 27u) % 3u) ? T_CRAC_EOB : T_LAC_0_EOB;
-    emit_int (c, value, 7, -1, 0, 3, 3, 4, 0, t, t, t, t);
-    break; }
+    b_int (d, value, 7, -1, 0, 3, 3, 4, 0, t, t, t, t);
+    return LH264_PRIOR (kind == LH264_SYM_NZ4 ? LH264_TB_NZ4 : LH264_TB_NZ8, prior) + 1u; }
   case LH264_SYM_AC4: case LH264_SYM_AC8: {                 // UEGkIntPrior<14,4,2,4,0>; tags by colour / first scan position (encode4x4)
     const uint32_t nco = kind == LH264_SYM_AC4 ? 16u : 64u;
     const uint32_t outer = prior / 3125u;
     const int emitted = (int) (outer % nco), color = (int) ((outer / nco) % 3u), code = (int) ((outer / nco / 3u) % 16u);
     const int first = color == 0 && emitted == 0 && code != 1;
     const int base = color ? T_CRAC_EOB : (first ? T_LAC_0_EOB : T_LAC_N_EOB);
-    touch_tag (c, base + 2);
-    cell_get (c, LH264_PRIOR (kind == LH264_SYM_AC4 ? LH264_TB_AC4 : LH264_TB_AC8, prior));
-    emit_uegk (c, value, 14, 4, 2, 4, 0, base + 2, base + 3, base + 1, base + 4);
-    break; }
+    touch = base + 2;                                        // encode4x4 bills to tag(..._EXP): the stream exists from then on
+    b_uegk (d, value, 14, 4, 2, 4, 0, base + 2, base + 3, base + 1, base + 4);
+    return LH264_PRIOR (kind == LH264_SYM_AC4 ? LH264_TB_AC4 : LH264_TB_AC8, prior) + 1u; }
+  case LH264_SYM_BIT:
+    push (d, 0, value != 0, pad);
+    return prior + 1u;
+  case LH264_SYM_RAW:
+    for (int i = 0; i < (int)prior; i++) push (d, 0xff, (value >> ((int)prior - 1 - i)) & 1, pad);
+    return 0u;
+  case LH264_SYM_MVD:                                       // UEGkIntPrior<9,4,3,4,3>
+    b_uegk (d, value, 9, 4, 3, 4, 3, pad, pad, pad, pad);
+    return prior + 1u;
   case LH264_SYM_TREE: {
     int nbits = 4, groups = 1;
     if (table == LH264_TB_SKIPRUN) { nbits = 9; groups = 32; } else if (table == LH264_TB_SUBMB) { nbits = 8; groups = 16; }
     else if (table == LH264_TB_CBPC) nbits = 2;
-    if (groups == 1) cell_get (c, prior);
-    emit_tree (c, prior, groups, 0, (unsigned) (uint16_t)value, nbits, pad);
-    break; }
+    b_tree (d, prior, groups, 0, (unsigned) (uint16_t)value, nbits, pad, -1);
+    return groups > 1 ? 0u : prior + 1u; }
   case LH264_SYM_POW2: {                                    // emitBitsZeroToPow2Inclusive<nbits>: priors[0], then the tree in priors[1..]
     const bool qpl = table == LH264_TB_QPL;
-    const int nbits = qpl ? 7 : 3, groups = qpl ? 8 : 1;
+    const int groups = qpl ? 8 : 1;
     const unsigned preferred = qpl ? 0u : index, data = (unsigned) (uint16_t)value;
-    cell_get (c, (prior & 0xf8000000u) | (index * (uint32_t)groups));
-    decide (c, 0, data != preferred, pad);
-    if (data != preferred) emit_tree (c, prior, groups, 1, data > preferred ? data - 1u : data, nbits, pad);
-    break; }
-  case LH264_SYM_BIT:
-    cell_get (c, prior);
-    decide (c, 0, value != 0, pad);
-    break;
-  case LH264_SYM_RAW:
-    for (int i = 0; i < (int)prior; i++) decide_raw (c, (value >> ((int)prior - 1 - i)) & 1, pad);
-    break;
-  case LH264_SYM_MVD:                                       // UEGkIntPrior<9,4,3,4,3>
-    cell_get (c, prior);
-    emit_uegk (c, value, 9, 4, 3, 4, 3, pad, pad, pad, pad);
-    break;
-  default: c.status = 2; break;
+    if (groups > 1) push_switch (d, (prior & 0xf8000000u) | (index * (uint32_t)groups));
+    push (d, 0, data != preferred, pad);
+    if (data != preferred) b_tree (d, prior, groups, 1, data > preferred ? data - 1u : data, qpl ? 7 : 3, pad, 0);
+    return groups > 1 ? 0u : prior + 1u; }
+  default: return 0u;
   }
+}
+
+// one decision: adaptive update of the cell in hand (or of TEST_PROB), then it goes to the lane owning its tag
+__device__ __forceinline__ void decide (Coder& c, uint32_t w) {
+  const int j = (int) (w & 0xffu), bit = (int) ((w >> 8) & 1u), tag = (int) ((w >> 16) & 0xffu);
+  int prob;
+  if (j == 0xff) { prob = dp_prob (c.test_prob); c.test_prob = dp_update (c.test_prob, bit); }
+  else {
+    const uint32_t s = (uint32_t)__builtin_amdgcn_readlane ((int)c.cellv, j);
+    prob = dp_prob (s);
+    const uint32_t ns = dp_update (s, bit);
+    if (c.lane == j) c.cellv = ns;
+  }
+  const int slot = tag_slot (tag);
+#ifndef LH264_CODER_ABL_NOBC
+  if (c.lane == slot) bc_write (c.bc, c.out + (size_t)slot * c.cap, c.cap, bit, prob);
+#else
+  if (c.lane == slot) c.bc.low += (uint32_t) (prob + bit);
+#endif
+}
+
+// Code a batch of up to 64 symbols held one per lane (sym = the 8-byte record).  Binarisation and memory latency are paid
+// once per batch: every lane builds the decision list of its own symbol, looks up the symbol's cell in the hash table and
+// fetches it into the wave's LDS rows, all in parallel; the decisions are then executed strictly in order, a cell shared by
+// several symbols of the batch living in the row of the first of them; cells not found (new priors) and priors spanning
+// several cells go to the table serially.
+__device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, uint32_t* bcell /* LDS [64][16] */, uint32_t* dl /* LDS [64][DL_STRIDE] */) {
+  const int lane = c.lane;
+  const uint32_t prior = (uint32_t)sym, hi = (uint32_t) (sym >> 32);
+  DList d; d.row = dl + lane * DL_STRIDE; d.n = 0;
+  int touch = -1;
+  uint32_t key = 0;
+  if (lane < count) key = build_symbol (d, prior, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24), touch);
+  if (d.n > DL_STRIDE) c.status = 8;
+  const int nd = d.n;
+  // the row of a cell = the first lane of the batch that uses it
+  int owner = lane;
+  for (int j = 0; j < count; j++) {
+    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane ((int)key, j);
+    if (kj == key && j < owner) owner = j;
+  }
+  // parallel probe + fetch by the owners
+  uint32_t slot = 0; bool found = false;
+  if (key != 0u && owner == lane) {
+    uint32_t h = ((key - 1u) * 0x9E3779B1u) >> 7;
+    for (int p = 0; p < 8; p++) {
+      const uint32_t s = (h + (uint32_t)p) & c.mask;
+      const uint32_t kv = c.keys[s];
+      if (kv == key) { slot = s; found = true; break; }
+      if (kv == 0u) break;
+    }
+    if (found) {
+      const GLB u32x4* src = (const GLB u32x4*) (c.cells + (size_t)slot * 16);
+      u32x4* dst = (u32x4*) (bcell + lane * 16);
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    }
+  }
+  unsigned long long valid = __ballot (found);
+  __builtin_amdgcn_wave_barrier();
+  for (int i = 0; i < count; i++) {
+    const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane ((int)key, i);
+    const int r = __builtin_amdgcn_readlane (owner, i);
+    const int ni = __builtin_amdgcn_readlane (nd, i);
+    const int ti = __builtin_amdgcn_readlane (touch, i);
+    if (ti >= 0) touch_tag (c, ti);
+    const uint32_t words = lane < ni ? dl[i * DL_STRIDE + lane] : 0u;      // the symbol's decisions, one per lane
+    if (ki) {
+      if ((valid >> r) & 1ull) c.cellv = lane < 16 ? bcell[r * 16 + lane] : 0u;
+      else {                       // not in the table yet (or probed too far away): find / insert serially
+        c.have_cell = false;
+        cell_get (c, ki - 1u);
+        const uint32_t sl = c.cur_slot;
+        if (lane == r) slot = sl;
+        valid |= 1ull << r;
+        c.have_cell = false;
+      }
+    }
+    for (int t = 0; t < ni; t++) {
+      const uint32_t w = (uint32_t)__builtin_amdgcn_readlane ((int)words, t);
+      if (w & 0x80000000u) {       // a prior spanning several cells: straight to the table and back
+        const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane ((int)words, t + 1);
+        cell_get (c, k2 - 1u);      // (writes the cell in hand back first)
+        t++;
+      } else decide (c, w);
+    }
+    if (ki) { if (lane < 16) bcell[r * 16 + lane] = c.cellv; }
+    else cell_flush (c);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // write the rows back
+  if (key != 0u && owner == lane && ((valid >> lane) & 1ull)) {
+    GLB u32x4* dst = (GLB u32x4*) (c.cells + (size_t)slot * 16);
+    const u32x4* src = (const u32x4*) (bcell + lane * 16);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 __global__ void __launch_bounds__ (64)
 coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __restrict__ chain_first,
                     const lh264_code_stream_t* __restrict__ streams, int n_chains) {
+  __shared__ uint32_t bcell[64 * 16];
+  __shared__ uint32_t dl[64 * DL_STRIDE];
+  __shared__ uint64_t queue[128];
   const int chain = blockIdx.x;
   if (chain >= n_chains) return;
   const lh264_code_stream_t* S = streams + chain;
@@ -263,32 +366,61 @@ coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __
   c.lane = (int)threadIdx.x;
   c.cellv = 0; c.cur_key = 0; c.cur_slot = 0; c.have_cell = false; c.test_prob = 0; c.status = 0;
   c.bc.used = 0; c.bc.pos = 0; c.bc.low = 0; c.bc.range = 255; c.bc.count = -24; c.bc.ffrun = 0; c.bc.pending = -1; c.bc.last = 0;
+  const int lane = c.lane;
+  // One loop, one copy of the coder: fill the queue from the stream's symbol sources (host list of macroblock k, with the
+  // coefficient symbols of macroblock k in place of the marker), then code a batch of up to 64.
   const int first = chain_first[chain], last = chain_first[chain + 1];
-  for (int ji = first; ji < last; ji++) {
-    const lh264_code_job_t* J = jobs + ji;
-    const GLB lh264_ctx_sym_t* hs = glb<const lh264_ctx_sym_t> (J->syn_syms_dev);
-    const GLB uint32_t* off = glb<const uint32_t> (J->syn_off_dev);
-    const GLB lh264_ctx_sym_t* cs = glb<const lh264_ctx_sym_t> (J->ctx_syms_dev);
-    const GLB uint16_t* cn = glb<const uint16_t> (J->ctx_n_syms_dev);
-    const int n = J->n_mbs;
-    for (int k = 0; k < n; k++) {
-      const uint32_t o0 = (uint32_t)uniform ((int)off[k]), o1 = (uint32_t)uniform ((int)off[k + 1]);
-      for (uint32_t si = o0; si < o1; si++) {
-        const uint64_t raw = * (const GLB uint64_t*) (hs + si);
-        const uint32_t prior = (uint32_t)uniform ((int) (uint32_t)raw);
-        const uint32_t hi = (uint32_t)uniform ((int) (uint32_t) (raw >> 32));
-        const int kind = (int) ((hi >> 16) & 0xffu);
-        if (kind == LH264_SYM_SPLICE) {
-          const int m = uniform ((int)cn[k]);
-          const GLB lh264_ctx_sym_t* q = cs + (size_t)k * LH264_CTX_MAX_SYMS;
-          for (int ci = 0; ci < m; ci++) {
-            const uint64_t r2 = * (const GLB uint64_t*) (q + ci);
-            const uint32_t p2 = (uint32_t)uniform ((int) (uint32_t)r2), h2 = (uint32_t)uniform ((int) (uint32_t) (r2 >> 32));
-            code_symbol (c, p2, (int) (int16_t) (h2 & 0xffffu), (int) ((h2 >> 16) & 0xffu), 0);
-          }
-        } else code_symbol (c, prior, (int) (int16_t) (hi & 0xffffu), kind, (int) (hi >> 24));
+  int ji = first, k = 0, n = 0, mc = 0, cb = 0;
+  uint32_t base = 0, o1 = 0;
+  bool in_ctx = false, have_job = false, have_mb = false;
+  const GLB uint64_t* hs = nullptr; const GLB uint32_t* off = nullptr; const GLB uint64_t* cs = nullptr; const GLB uint16_t* cn = nullptr;
+  int qn = 0;
+  for (;;) {
+    // ---- fill ---------------------------------------------------------------------------------------------------------
+    while (qn < 64) {
+      if (!have_job) {
+        if (ji >= last) break;
+        const lh264_code_job_t* J = jobs + ji;
+        hs = glb<const uint64_t> (J->syn_syms_dev); off = glb<const uint32_t> (J->syn_off_dev);
+        cs = glb<const uint64_t> (J->ctx_syms_dev); cn = glb<const uint16_t> (J->ctx_n_syms_dev);
+        n = J->n_mbs; k = 0; have_job = true; have_mb = false;
       }
+      if (!have_mb) {
+        if (k >= n) { have_job = false; ji++; continue; }
+        base = (uint32_t)uniform ((int)off[k]); o1 = (uint32_t)uniform ((int)off[k + 1]);
+        have_mb = true; in_ctx = false;
+      }
+      const int space = 128 - qn;
+      if (in_ctx) {
+        int t2 = mc - cb; if (t2 > 64) t2 = 64; if (t2 > space) t2 = space;
+        if (t2 > 0) {
+          const uint64_t cv = lane < t2 ? cs[(size_t)k * LH264_CTX_MAX_SYMS + cb + lane] : 0ull;
+          if (lane < t2) queue[qn + lane] = cv;
+          qn += t2; cb += t2;
+        }
+        if (cb >= mc) in_ctx = false;
+        continue;
+      }
+      if (base >= o1) { have_mb = false; k++; continue; }
+      int m = (int) (o1 - base); if (m > 64) m = 64; if (m > space) m = space;
+      const uint64_t hv = lane < m ? hs[base + lane] : 0ull;
+      const unsigned long long spl = __ballot (lane < m && ((hv >> 48) & 0xffull) == (unsigned long long)LH264_SYM_SPLICE);
+      const int take = spl ? __ffsll ((long long)spl) - 1 : m;          // symbols before the marker (or all of them)
+      if (lane < take) queue[qn + lane] = hv;
+      qn += take; base += (uint32_t)take;
+      if (spl) { base++; mc = uniform ((int)cn[k]); cb = 0; in_ctx = mc > 0; }
     }
+    if (qn == 0) break;
+    // ---- code ---------------------------------------------------------------------------------------------------------
+    __builtin_amdgcn_wave_barrier();
+    const int m = qn < 64 ? qn : 64;
+    const uint64_t sym = lane < m ? queue[lane] : 0ull;
+    const uint64_t mv = queue[64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    code_batch (c, sym, m, bcell, dl);
+    if (qn > 64) queue[lane] = mv;                   // what is left moves to the front
+    qn -= m;
+    __builtin_amdgcn_wave_barrier();
   }
   cell_flush (c);
   GLB uint32_t* lens = glb<uint32_t> (S->out_len_dev);

@@ -8,7 +8,7 @@ for d in sys.argv[1:]:
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             k = r["Kernel_Name"].split("(")[0]
-            if "chain_kernel" in k or "ctx_" in k or "recon_" in k:
+            if "chain_kernel" in k or "ctx_" in k or "recon_" in k or "coder_" in k:
                 acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 print("kernel,counter,dispatches,mean_per_dispatch")
 for (k, c), v in sorted(acc.items()):
