@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t dp_update (uint32_t s, int bit) {
   // floor (256 (c0+1) / (c0+c1+2)) < 256: numerator < 2^18,
   // divisor <= 516: a float quotient is within one of the exact one
   const uint32_t num = 256u * (c0 + 1u), den = c0 + c1 + 2u;
-  uint32_t prob = (uint32_t) ((float)num * __frcp_rn ((float)den));
+  uint32_t prob = (uint32_t) ((float)num * __builtin_amdgcn_rcpf ((float)den));
   if (prob * den > num) prob--;
   else if ((prob + 1u) * den <= num) prob++;
   if (c0 + c1 > 512u) { c0 = (c0 + 1u) >> 1; c1 = (c1 + 1u) >> 1; }
@@ -203,7 +203,7 @@ __device__ __forceinline__ void b_tree (DList& d, uint32_t prior, int groups, un
   }
 }
 
-// one symbol -> its decision list; returns the key (+1) of its cell when it uses exactly one (0: none or switches inside);
+// one symbol -> its decision list; returns the key (+1) of its (first) cell, 0 if it has none (raw bits);
 // touch: the tag the symbol brings into existence (or -1)
 __device__ __forceinline__ uint32_t build_symbol (DList& d, uint32_t prior, int value, int kind, int pad, int& touch) {
   enum { T_LDC = 17, T_CRDC = 18, T_LAC_0_EOB = 19, T_LAC_N_EOB = 24, T_CRAC_EOB = 29 };
@@ -241,16 +241,15 @@ __device__ __forceinline__ uint32_t build_symbol (DList& d, uint32_t prior, int 
     int nbits = 4, groups = 1;
     if (table == LH264_TB_SKIPRUN) { nbits = 9; groups = 32; } else if (table == LH264_TB_SUBMB) { nbits = 8; groups = 16; }
     else if (table == LH264_TB_CBPC) nbits = 2;
-    b_tree (d, prior, groups, 0, (unsigned) (uint16_t)value, nbits, pad, -1);
-    return groups > 1 ? 0u : prior + 1u; }
+    b_tree (d, prior, groups, 0, (unsigned) (uint16_t)value, nbits, pad, 0);
+    return ((prior & 0xf8000000u) | (index * (uint32_t)groups)) + 1u; }     // the cell of the tree's first 16 nodes
   case LH264_SYM_POW2: {                                    // emitBitsZeroToPow2Inclusive<nbits>: priors[0], then the tree in priors[1..]
     const bool qpl = table == LH264_TB_QPL;
     const int groups = qpl ? 8 : 1;
     const unsigned preferred = qpl ? 0u : index, data = (unsigned) (uint16_t)value;
-    if (groups > 1) push_switch (d, (prior & 0xf8000000u) | (index * (uint32_t)groups));
     push (d, 0, data != preferred, pad);
     if (data != preferred) b_tree (d, prior, groups, 1, data > preferred ? data - 1u : data, qpl ? 7 : 3, pad, 0);
-    return groups > 1 ? 0u : prior + 1u; }
+    return ((prior & 0xf8000000u) | (index * (uint32_t)groups)) + 1u; }
   default: return 0u;
   }
 }
@@ -298,16 +297,21 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
   uint32_t slot = 0; bool found = false;
   if (key != 0u && owner == lane) {
     uint32_t h = ((key - 1u) * 0x9E3779B1u) >> 7;
-    for (int p = 0; p < 8; p++) {
+    bool fresh = false;
+    for (int p = 0; p < 16; p++) {
       const uint32_t s = (h + (uint32_t)p) & c.mask;
-      const uint32_t kv = c.keys[s];
+      uint32_t kv = c.keys[s];
+      if (kv == 0u) kv = atomicCAS ((uint32_t*) (uintptr_t) (c.keys + s), 0u, key);      // a new prior: claim the slot (other lanes insert too)
       if (kv == key) { slot = s; found = true; break; }
-      if (kv == 0u) break;
+      if (kv == 0u) { slot = s; found = true; fresh = true; break; }
     }
     if (found) {
-      const GLB u32x4* src = (const GLB u32x4*) (c.cells + (size_t)slot * 16);
       u32x4* dst = (u32x4*) (bcell + lane * 16);
-      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      if (fresh) { const u32x4 z = {0u, 0u, 0u, 0u}; dst[0] = z; dst[1] = z; dst[2] = z; dst[3] = z; }      // zero = the initial state
+      else {
+        const GLB u32x4* src = (const GLB u32x4*) (c.cells + (size_t)slot * 16);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      }
     }
   }
   unsigned long long valid = __ballot (found);
@@ -330,15 +334,17 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
         c.have_cell = false;
       }
     }
+    bool in_row = ki != 0u;
     for (int t = 0; t < ni; t++) {
       const uint32_t w = (uint32_t)__builtin_amdgcn_readlane ((int)words, t);
-      if (w & 0x80000000u) {       // a prior spanning several cells: straight to the table and back
+      if (w & 0x80000000u) {       // the tree leaves its first cell: the others go straight to the table and back
         const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane ((int)words, t + 1);
-        cell_get (c, k2 - 1u);      // (writes the cell in hand back first)
+        if (in_row) { if (lane < 16) bcell[r * 16 + lane] = c.cellv; in_row = false; c.have_cell = false; }
+        cell_get (c, k2 - 1u);      // (writes a previous out-of-row cell back first)
         t++;
       } else decide (c, w);
     }
-    if (ki) { if (lane < 16) bcell[r * 16 + lane] = c.cellv; }
+    if (in_row) { if (lane < 16) bcell[r * 16 + lane] = c.cellv; }
     else cell_flush (c);
   }
   __builtin_amdgcn_wave_barrier();
