@@ -499,7 +499,7 @@ struct Parser::Impl {
   }
   inline int dq8 (const Pps& P, bool use_sl, int list8, int qp, int j, int level) const {
     const int d = (use_sl ? P.sl8[list8][j] : 16) * kNormAdjust8x8[qp % 6][cls8 (j & 7, j >> 3)];
-    return qp >= 36 ? (level * d) << (qp / 6 - 6) : (level * d + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+    return qp >= 36 ? (level * d) * (1 << (qp / 6 - 6)) : (level * d + (1 << (5 - qp / 6))) >> (6 - qp / 6);
   }
 
   // median motion vector prediction (8.4.1.3) on the 4x4-granular state

@@ -18,10 +18,11 @@ class ReconSession:
     streams: list of streams; a stream is a list of frames; a frame is an object with
       mb_w, mb_h, mbs (MB_DTYPE[n]), coeffs (int16[n,384]), slices (SLICE_DTYPE[k]), id, ref_ids
     (exactly what tests/golden_io.py / tests/refdump.py return, or what the host parser emits).
-    Every frame gets its own padded picture in HBM (sized for 288 GB parts; a DPB ring is a host policy).
+    Every frame gets its own padded picture in HBM (sized for 288 GB parts); ring=N instead reuses N picture buffers
+    cyclically per stream, the way a decoded-picture-buffer host policy would (frames of one size only).
     """
 
-    def __init__(self, streams, device=0, flags=0, replicate=1, share_records=True):
+    def __init__(self, streams, device=0, flags=0, replicate=1, share_records=True, ring=0):
         torch = _torch()
         self.torch = torch
         self.lib = L.lib()
@@ -63,9 +64,12 @@ class ReconSession:
         self.geo = {}
         for c in range(self.n_chains):
             offs = []
-            for (_, _, _, w, h, _, _) in self.frame_info[c % len(streams)]:
+            for fi_, (_, _, _, w, h, _, _) in enumerate(self.frame_info[c % len(streams)]):
                 if (w, h) not in self.geo:
                     self.geo[(w, h)] = L.pic_geometry(w, h)
+                if ring and fi_ >= ring:
+                    offs.append(offs[fi_ - ring])
+                    continue
                 offs.append(total)
                 total += (self.geo[(w, h)][5] + 255) & ~255
             self.pic_off.append(offs)

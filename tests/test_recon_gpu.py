@@ -129,3 +129,53 @@ def test_parser_to_gpu_sha1():
                 s = 1 if p else 0
                 h.update(np.ascontiguousarray(got[p][f.crop_y >> s:(f.crop_y + f.crop_h) >> s, f.crop_x >> s:(f.crop_x + f.crop_w) >> s]).tobytes())
         assert h.hexdigest() == sha[name], name
+
+
+def test_chain_with_resolution_change():
+    """frames of different sizes in one chain (the row cursor of the pipelined wavefront crosses pictures of different
+    heights; a new intra picture starts each segment, as after an SPS change)"""
+    import losslessh264_amd as lh
+    a = synth.make_stream(seed=31, mb_w=6, mb_h=5, n_frames=3)
+    b = synth.make_stream(seed=32, mb_w=4, mb_h=11, n_frames=3)
+    c = synth.make_stream(seed=33, mb_w=9, mb_h=2, n_frames=2)
+    frames = []
+    for seg in (a, b, c):
+        base = len(frames)
+        for f in seg:
+            f.id += base
+            f.ref_ids = [r + base for r in f.ref_ids]
+            frames.append(f)
+    sess = lh.ReconSession([frames])
+    sess.run(); sess.synchronize()
+    _compare(sess, 0, frames, _oracle_stream(frames), padded=True)
+
+
+@pytest.mark.parametrize("ring", [4, 5])
+def test_picture_buffers_reused_as_a_ring(ring):
+    """a DPB-ring host policy: with 4 buffers the picture a frame writes is still a reference of the previous frame (the
+    kernel must not overlap the two frames), with 5 it is not (frames overlap)"""
+    import losslessh264_amd as lh
+    frames = synth.make_stream(seed=41, mb_w=7, mb_h=9, n_frames=9)
+    sess = lh.ReconSession([frames], ring=ring)
+    sess.run(); sess.synchronize()
+    ref = _oracle_stream(frames)
+    for i in range(len(frames) - ring, len(frames)):          # the pictures still resident
+        got = sess.picture(0, i, padded=True)
+        for p in range(3):
+            assert np.array_equal(got[p], ref[i].padded_plane(p)), (ring, i, p)
+
+
+def test_lost_macroblocks_pass_the_picture_through():
+    """macroblocks no slice covers (mb_type 0) keep the picture's current samples and are not filtered"""
+    import losslessh264_amd as lh
+    frames = synth.make_stream(seed=51, mb_w=6, mb_h=4, n_frames=1, p_frames=False, n_slices=2)
+    f = frames[0]
+    lost = np.arange(f.slices["first_mb"][1], f.slices["first_mb"][1] + f.slices["n_mbs"][1])
+    f.mbs["mb_type"][lost] = 0
+    f.slices = f.slices[:1].copy()
+    sess = lh.ReconSession([frames])
+    sess.run(); sess.synchronize()
+    _compare(sess, 0, frames, _oracle_stream(frames))
+    got = sess.picture(0, 0)
+    y0 = (int(lost[0]) // f.mb_w + 1) * 16
+    assert (got[0][y0:] == 128).all()                          # rows entirely inside the lost slice keep the fill value
