@@ -3,6 +3,7 @@
 // group -- the subset the reference decoder itself supports.
 #include "h264_parser.h"
 #include "pip_symbols.h"
+#include "h264_cabac_tables.h"
 #include <string.h>
 #include <algorithm>
 #include "h264_tables.h"
@@ -42,6 +43,52 @@ struct MbState {       // per-macroblock parse state of the current picture (nei
   int8_t ipm[16];           // Intra4x4PredMode per raster 4x4 (I8x8: replicated), 2 otherwise
   int8_t ref[4];
   int16_t mv[16][2];
+  // CABAC context inputs (9.3.3.1.1)
+  uint8_t skip = 0, pcm = 0, t8 = 0, cbp = 0, chroma_pred = 0;
+  uint8_t mvd[16][2];       // |mvd| per 4x4 block, saturated
+  uint32_t cbf = 0;         // coded_block_flag: bits 0..15 luma 4x4 (raster), 16 luma DC, 17/18 chroma DC, 19..22 Cb AC, 23..26 Cr AC
+};
+
+// ---- CABAC arithmetic decoding engine (9.3.1.2, 9.3.3.2) -----------------------------------------------------------------
+struct Cabac {
+  const uint8_t* p = nullptr; size_t nbits = 0, pos = 0;
+  uint32_t range = 510, offset = 0;
+  uint8_t state[460];        // pStateIdx << 1 | valMPS
+  bool err = false;
+  inline uint32_t bit() { if (pos >= nbits) { pos++; if (pos > nbits + 64) err = true; return 0; } const uint32_t b = (p[pos >> 3] >> (7 - (pos & 7))) & 1; pos++; return b; }
+  void start (const uint8_t* d, size_t bytes, size_t bitpos) {
+    p = d; nbits = bytes * 8; pos = bitpos; range = 510; offset = 0;
+    for (int i = 0; i < 9; i++) offset = (offset << 1) | bit();
+  }
+  void init_contexts (int col, int qp) {
+    qp = std::min (51, std::max (0, qp));
+    for (int i = 0; i < 460; i++) {
+      const int m = kCabacInit[i][col][0], n = kCabacInit[i][col][1];
+      const int pre = std::min (126, std::max (1, ((m * qp) >> 4) + n));
+      state[i] = pre <= 63 ? (uint8_t) ((63 - pre) << 1) : (uint8_t) (((pre - 64) << 1) | 1);
+    }
+  }
+  inline int decode (int ctx) {
+    uint8_t& s = state[ctx];
+    const int st = s >> 1; int mps = s & 1;
+    const uint32_t lps = kCabacRangeLps[st][(range >> 6) & 3];
+    range -= lps;
+    int b;
+    if (offset >= range) {
+      b = !mps; offset -= range; range = lps;
+      if (st == 0) mps = !mps;
+      s = (uint8_t) ((kCabacNextLps[st] << 1) | mps);
+    } else { b = mps; s = (uint8_t) ((kCabacNextMps[st] << 1) | mps); }
+    while (range < 256) { range <<= 1; offset = (offset << 1) | bit(); }
+    return b;
+  }
+  inline int bypass() { offset = (offset << 1) | bit(); if (offset >= range) { offset -= range; return 1; } return 0; }
+  inline int terminate() {
+    range -= 2;
+    if (offset >= range) return 1;
+    while (range < 256) { range <<= 1; offset = (offset << 1) | bit(); }
+    return 0;
+  }
 };
 
 }  // namespace
@@ -344,7 +391,12 @@ struct Parser::Impl {
     if (first_sh.nal_ref_idc) { mark_reference (first_sh, *csps); cur->is_ref = true; prev_ref_frame_num = had_mmco5 ? 0 : first_sh.frame_num; }
     had_mmco5 = false;
     for (const auto& d : dpb) cur->dpb_ids.push_back (d.frame_id);
-    if (cur->slice_syn.size() == cur->slices.size()) symbolizer.picture (*cur);
+    {   // the row-a10 symbol lists exist for CAVLC pictures (the CABAC variant of the reference's emit code is not restated)
+      bool cavlc = cur->slice_syn.size() == cur->slices.size();
+      for (const auto& ss : cur->slice_syn) cavlc = cavlc && !ss.cabac;
+      if (cavlc) symbolizer.picture (*cur);
+      else { cur->syn_off.assign ((size_t)cur->mb_w * cur->mb_h + 1, 0); cur->syn_syms.clear(); }
+    }
     cur->complete = true;
     self->frames_.push_back (std::move (cur));
     cur.reset();
@@ -546,6 +598,9 @@ struct Parser::Impl {
   }
 
   bool parse_slice_data_cavlc (BitReader& br, SliceCtx& c);
+  bool parse_slice_data_cabac (BitReader& br, SliceCtx& c);
+  bool parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, int& last_dqp, bool is_skip);
+  int cabac_residual (Cabac& cb, int k, int sid, int cat, int blk /*luma raster 4x4, chroma block 0..3, or plane for DC*/, int plane, bool cur_intra, int* lv, int maxc);
   bool parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_prev, bool is_skip);
   void finalize_intra_modes (SliceCtx& c, int k, const int* raw4 /*16 raster or null*/, bool is8, int i16mode, int chroma_mode);
 
@@ -876,6 +931,461 @@ bool Parser::Impl::parse_slice_data_cavlc (BitReader& br, SliceCtx& c) {
   return true;
 }
 
+// ---- CABAC macroblock layer (7.3.5 with the binarisations and context selection of 9.3.2 / 9.3.3) ------------------------
+namespace {
+// ctxIdxInc of significant_coeff_flag (frame coded) and last_significant_coeff_flag for 8x8 blocks, Table 9-43
+const uint8_t kSig8x8[63] = {0, 1, 2, 3, 4, 5, 5, 4, 4, 3, 3, 4, 4, 4, 5, 5, 4, 4, 4, 4, 3, 3, 6, 7, 7, 7, 8, 9, 10, 9, 8, 7, 7, 6, 11, 12, 13, 11, 6, 7, 8, 9,
+                             14, 10, 9, 8, 6, 11, 12, 13, 11, 6, 9, 14, 10, 9, 11, 12, 13, 11, 14, 10, 12};
+const uint8_t kLast8x8[63] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3,
+                              4, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8};
+const int kCatCbf[5] = {0, 4, 8, 12, 16}, kCatMap[5] = {0, 15, 29, 44, 47}, kCatAbs[5] = {0, 10, 20, 30, 39};
+}  // namespace
+
+// one residual block (7.3.5.3.3): returns the number of nonzero coefficients, levels in scan order in lv[0..maxc-1]
+int Parser::Impl::cabac_residual (Cabac& cb, int k, int sid, int cat, int blk, int plane, bool cur_intra, int* lv, int maxc) {
+  const int w = cur->mb_w;
+  MbState& s = st[k];
+  for (int i = 0; i < maxc; i++) lv[i] = 0;
+  if (cat != 5) {
+    // coded_block_flag, ctxIdxInc = condTermFlagA + 2 condTermFlagB (9.3.3.1.1.9)
+    int bit, bitA, bitB; int kA = k, kB = k;
+    if (cat == 0) { bit = bitA = bitB = 16; kA = -2; kB = -2; }
+    else if (cat == 3) { bit = bitA = bitB = 17 + plane; kA = -2; kB = -2; }
+    else if (cat == 4) {
+      const int cx = blk & 1, cy = blk >> 1;
+      bit = 19 + plane * 4 + blk;
+      if (cx == 0) { kA = -2; bitA = 19 + plane * 4 + cy * 2 + 1; } else bitA = bit - 1;
+      if (cy == 0) { kB = -2; bitB = 19 + plane * 4 + 2 + cx; } else bitB = bit - 2;
+    } else {
+      const int bx = blk & 3, by = blk >> 2;
+      bit = blk;
+      if (bx == 0) { kA = -2; bitA = by * 4 + 3; } else bitA = blk - 1;
+      if (by == 0) { kB = -2; bitB = 12 + bx; } else bitB = blk - 4;
+    }
+    if (kA == -2) kA = ((k % w) && mb_avail (k - 1, sid)) ? k - 1 : -1;
+    if (kB == -2) kB = (k >= w && mb_avail (k - w, sid)) ? k - w : -1;
+    const int cA = kA < 0 ? (cur_intra ? 1 : 0) : (int) ((st[kA].cbf >> bitA) & 1);
+    const int cBf = kB < 0 ? (cur_intra ? 1 : 0) : (int) ((st[kB].cbf >> bitB) & 1);
+    if (!cb.decode (85 + kCatCbf[cat] + cA + 2 * cBf)) return 0;
+    s.cbf |= 1u << bit;
+  }
+  const int sig_base = cat == 5 ? 402 : 105 + kCatMap[cat], last_base = cat == 5 ? 417 : 166 + kCatMap[cat];
+  const int abs_base = cat == 5 ? 426 : 227 + kCatAbs[cat];
+  uint8_t sig[64];
+  int n_sig = 0, i;
+  for (i = 0; i < maxc - 1; i++) {
+    const int inc_s = cat == 5 ? kSig8x8[i] : cat == 3 ? std::min (i, 2) : i;
+    const int inc_l = cat == 5 ? kLast8x8[i] : cat == 3 ? std::min (i, 2) : i;
+    if (cb.decode (sig_base + inc_s)) {
+      sig[n_sig++] = (uint8_t)i;
+      if (cb.decode (last_base + inc_l)) break;
+    }
+  }
+  if (i == maxc - 1) sig[n_sig++] = (uint8_t) (maxc - 1);      // the last position is significant by inference
+  int num_eq1 = 0, num_gt1 = 0;
+  for (int j = n_sig - 1; j >= 0; j--) {
+    int inc = num_gt1 ? 0 : std::min (4, 1 + num_eq1);
+    int v = 0;                                                   // coeff_abs_level_minus1: TU prefix (cMax 14) + EG0 suffix
+    if (cb.decode (abs_base + inc)) {
+      v = 1;
+      inc = 5 + std::min (4 - (cat == 3 ? 1 : 0), num_gt1);
+      while (v < 14 && cb.decode (abs_base + inc)) v++;
+      if (v == 14) {
+        int kk = 0;
+        while (cb.bypass()) { v += 1 << kk; kk++; if (kk > 24) { cb.err = true; break; } }
+        while (kk--) v += cb.bypass() << kk;
+      }
+    }
+    const int mag = v + 1;
+    lv[sig[j]] = cb.bypass() ? -mag : mag;
+    if (mag == 1) num_eq1++; else num_gt1++;
+  }
+  return n_sig;
+}
+
+bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, int& last_dqp, bool is_skip) {
+  const Sps& S = *c.S; const Pps& P = *c.P; const SliceHeader& sh = *c.sh;
+  const int sid = c.sid, w = cur->mb_w;
+  lh264_mb_t& m = cur->mbs[k];
+  MbState& s = st[k];
+  memset (&m, 0, sizeof (m));
+  m.slice_id = (uint16_t)sid;
+  s.slice = (int16_t)sid;
+  cur->covered[k] = 1;
+  for (int i = 0; i < 16; i++) { s.ipm[i] = 2; s.mv[i][0] = s.mv[i][1] = 0; s.mvd[i][0] = s.mvd[i][1] = 0; }
+  for (int i = 0; i < 4; i++) { s.ref[i] = -1; m.ref_idx[i] = -1; }
+  s.skip = 0; s.pcm = 0; s.t8 = 0; s.cbp = 0; s.chroma_pred = 0; s.cbf = 0;
+  int16_t* coef = &cur->coeffs[(size_t)k * 384];
+  int16_t* lev = &cur->levels[(size_t)k * 384];
+  const bool use_sl = S.scaling_matrix_present || P.scaling_matrix_present;
+  const int kA = ((k % w) && mb_avail (k - 1, sid)) ? k - 1 : -1, kB = (k >= w && mb_avail (k - w, sid)) ? k - w : -1;
+  auto set_qp = [&] (int qp) {
+    m.qp_y = (uint8_t)qp;
+    for (int p = 0; p < 2; p++) m.qp_c[p] = kChromaQp[std::min (51, std::max (0, qp + P.chroma_qp_offset[p]))];
+  };
+  auto fill_part = [&] (int bx, int by, int bw, int bh, int mvx, int mvy, int dx, int dy, uint32_t& filled) {
+    const uint8_t ax = (uint8_t)std::min (255, std::abs (dx)), ay = (uint8_t)std::min (255, std::abs (dy));
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) {
+        s.mv[y * 4 + x][0] = (int16_t)mvx; s.mv[y * 4 + x][1] = (int16_t)mvy;
+        m.mv[y * 4 + x][0] = (int16_t)mvx; m.mv[y * 4 + x][1] = (int16_t)mvy;
+        s.mvd[y * 4 + x][0] = ax; s.mvd[y * 4 + x][1] = ay;
+        filled |= 1u << (y * 4 + x);
+      }
+  };
+  MbSyn& y = cur->syn[k];
+  memset (&y, 0, sizeof (y));
+  if (is_skip) {                                        // P_Skip
+    m.mb_type = LH264_MB_SKIP; s.type_class = 3; s.skip = 1;
+    for (int i = 0; i < 4; i++) { s.ref[i] = 0; m.ref_idx[i] = 0; }
+    Nb A = nb_block (k, -1, 0, sid, 0), B = nb_block (k, 0, -1, sid, 0);
+    int px = 0, py = 0;
+    if (A.avail && B.avail && !(A.ref == 0 && A.mvx == 0 && A.mvy == 0) && !(B.ref == 0 && B.mvx == 0 && B.mvy == 0))
+      predict_mv (k, sid, 0, 0, 0, 4, 0, 0, px, py);
+    uint32_t filled = 0;
+    fill_part (0, 0, 4, 4, px, py, 0, 0, filled);
+    set_qp (qp_prev);
+    last_dqp = 0;
+    return true;
+  }
+  y.have = 1; y.slice_type = (uint8_t)sh.slice_type; y.num_ref_idx_l0 = (uint32_t)sh.num_ref_idx_l0;
+  y.skip_run = slice_run_before; y.last_mb_qp = qp_prev;
+  struct SynDone {
+    Impl* d; MbSyn& y; lh264_mb_t& m; int k;
+    ~SynDone() {
+      y.mb_type = m.mb_type; y.t8 = (m.flags & LH264_MBF_T8x8) ? 1 : 0; y.cbp_c = m.cbp >> 4; y.cbp_l = m.cbp & 15; y.luma_qp = m.qp_y;
+      if (m.mb_type == LH264_MB_I4x4 || m.mb_type == LH264_MB_I8x8 || m.mb_type == LH264_MB_I16x16) d->persist_chroma[k] = (uint8_t)m.chroma_mode;
+      if (m.mb_type == LH264_MB_I16x16) d->persist_l16[k] = (uint8_t)m.intra_mode[0];
+      if (m.mb_type == LH264_MB_P8x8 || m.mb_type == LH264_MB_P8x8REF0) memcpy (&d->persist_sub[(size_t)k * 4], m.sub_type, 4);
+      y.chroma_mode = d->persist_chroma[k]; y.luma16_mode = d->persist_l16[k];
+      memcpy (y.sub_type, &d->persist_sub[(size_t)k * 4], 4);
+      y.delta_qp = (int)m.qp_y - d->slice_cached_qp;
+      d->slice_cached_qp = m.qp_y;
+    }
+  } syn_done = {this, y, m, k};
+
+  // ---- mb_type (9.3.2.5, 9.3.3.1.1.3) --------------------------------------------------------------------------------------
+  auto i_type = [&] (bool islice) -> int {           // I-slice binarisation, or the suffix of an intra macroblock in a P slice
+    int b0;
+    if (islice) {
+      const int cA = kA >= 0 && st[kA].type_class != 1, cBn = kB >= 0 && st[kB].type_class != 1;       // neighbour is not I_NxN
+      b0 = cb.decode (3 + cA + cBn);
+    } else b0 = cb.decode (17);
+    if (!b0) return 0;
+    if (cb.terminate()) return 25;
+    const int base = islice ? 3 : 17;
+    const int luma = cb.decode (base + (islice ? 3 : 1));
+    const int b3 = cb.decode (base + (islice ? 4 : 2));
+    int chroma = 0;
+    if (b3) chroma = cb.decode (base + (islice ? 5 : 2)) ? 2 : 1;
+    const int p0 = cb.decode (base + (islice ? (b3 ? 6 : 6) : 3)), p1 = cb.decode (base + (islice ? 7 : 3));
+    return 1 + (p0 << 1 | p1) + 4 * chroma + 12 * luma;
+  };
+  uint32_t mbt;
+  bool intra = true;
+  if (sh.slice_type == 2) mbt = (uint32_t)i_type (true);
+  else if (cb.decode (14)) mbt = (uint32_t)i_type (false);
+  else {
+    intra = false;
+    if (!cb.decode (15)) mbt = cb.decode (16) ? 3 : 0;
+    else mbt = cb.decode (17) ? 1 : 2;
+  }
+  if (cb.err) return false;
+  int cbp = 0;
+  bool t8 = false;
+  int raw_modes[16]; bool have_raw = false; int i16mode = -1, chroma_mode = -1;
+  auto chroma_pred = [&] () -> int {                  // intra_chroma_pred_mode, 9.3.3.1.1.8
+    const int cA = kA >= 0 && st[kA].type_class != 3 && !st[kA].pcm && st[kA].chroma_pred != 0;
+    const int cBn = kB >= 0 && st[kB].type_class != 3 && !st[kB].pcm && st[kB].chroma_pred != 0;
+    if (!cb.decode (64 + cA + cBn)) return 0;
+    if (!cb.decode (67)) return 1;
+    return cb.decode (67) ? 3 : 2;
+  };
+  if (intra) {
+    if (mbt == 25) {                                    // I_PCM: the samples follow byte aligned, then the engine restarts (9.3.1.2)
+      m.mb_type = LH264_MB_IPCM; s.type_class = 2; s.pcm = 1; s.cbf = 0xffffffffu; s.cbp = 0x2f;
+      size_t bp = (cb.pos + 7) & ~ (size_t)7;
+      for (int i = 0; i < 384; i++, bp += 8) coef[i] = (int16_t) (bp + 8 <= cb.nbits ? cb.p[bp >> 3] : 0);
+      if (bp > cb.nbits) cb.err = true;
+      cb.start (cb.p, cb.nbits / 8, bp);
+      m.flags |= LH264_MBF_PCM_IN_COEFF;
+      memset (m.nzc, 16, 24);
+      m.qp_y = 0; m.qp_c[0] = m.qp_c[1] = 0;
+      finalize_intra_modes (c, k, nullptr, false, -1, -1);
+      last_dqp = 0;
+      return !cb.err;
+    }
+    if (mbt == 0) {                                     // I_NxN
+      if (P.transform_8x8) {
+        const int cA = kA >= 0 && st[kA].t8, cBn = kB >= 0 && st[kB].t8;
+        t8 = cb.decode (399 + cA + cBn);
+      }
+      m.mb_type = t8 ? LH264_MB_I8x8 : LH264_MB_I4x4; s.type_class = 1; s.t8 = t8;
+      const int nblk = t8 ? 4 : 16;
+      for (int i = 0; i < nblk; i++) {
+        const int bx = t8 ? (i & 1) * 2 : z2x (i), by = t8 ? (i >> 1) * 2 : z2y (i);
+        int modeA = 2, modeB = 2; bool dcpred = false;
+        {
+          int kk = k, x = bx - 1, yy = by;
+          if (x < 0) { kk = (k % w) ? k - 1 : -1; x = 3; }
+          if (kk != k && !intra_nb_avail (kk, sid, P.constrained_intra_pred)) dcpred = true;
+          else modeA = (kk == k || st[kk].type_class == 1) ? st[kk].ipm[yy * 4 + x] : 2;
+        }
+        {
+          int kk = k, x = bx, yy = by - 1;
+          if (yy < 0) { kk = k >= w ? k - w : -1; yy = 3; }
+          if (kk != k && !intra_nb_avail (kk, sid, P.constrained_intra_pred)) dcpred = true;
+          else modeB = (kk == k || st[kk].type_class == 1) ? st[kk].ipm[yy * 4 + x] : 2;
+        }
+        const int pred = dcpred ? 2 : std::min (modeA, modeB);
+        int mode = pred;
+        if (!cb.decode (68)) { const int rem = cb.decode (69) | cb.decode (69) << 1 | cb.decode (69) << 2; mode = rem < pred ? rem : rem + 1; }
+        const int n = t8 ? 2 : 1;
+        y.pred_mode[i] = (int8_t)mode;
+        for (int yy = 0; yy < n; yy++) for (int x = 0; x < n; x++) { s.ipm[(by + yy) * 4 + bx + x] = (int8_t)mode; raw_modes[(by + yy) * 4 + bx + x] = mode; }
+      }
+      have_raw = true;
+      chroma_mode = chroma_pred();
+    } else {                                            // Intra16x16
+      m.mb_type = LH264_MB_I16x16; s.type_class = 2;
+      i16mode = (mbt - 1) & 3;
+      cbp = (((mbt - 1) >> 2) % 3) << 4 | ((mbt - 1) >= 12 ? 15 : 0);
+      chroma_mode = chroma_pred();
+    }
+    s.chroma_pred = (uint8_t)chroma_mode;
+  } else {                                              // P macroblocks
+    s.type_class = 3;
+    static const uint16_t kType[4] = {LH264_MB_P16x16, LH264_MB_P16x8, LH264_MB_P8x16, LH264_MB_P8x8};
+    m.mb_type = kType[mbt];
+    const int nref = sh.num_ref_idx_l0;
+    uint32_t filled = 0;
+    // ref_idx_l0 of the partition whose first 4x4 block is (bx,by): ctxIdxInc from the partitions to the left and above
+    auto ref_gt0 = [&] (int bx, int by) -> int {
+      int kk = k, x = bx, yy = by;
+      if (x < 0) { kk = kA; x = 3; } else if (yy < 0) { kk = kB; yy = 3; }
+      if (kk < 0) return 0;
+      const MbState& t = st[kk];
+      if (t.type_class != 3 || t.skip) return 0;
+      return t.ref[(yy >> 1) * 2 + (x >> 1)] > 0;
+    };
+    auto read_ref = [&] (int bx, int by) -> int {
+      if (nref <= 1) return 0;
+      int inc = ref_gt0 (bx - 1, by) + 2 * ref_gt0 (bx, by - 1), v = 0;
+      while (cb.decode (54 + inc)) { v++; inc = v == 1 ? 4 : 5; if (v > 32) { cb.err = true; break; } }
+      return v;
+    };
+    auto abs_mvd = [&] (int bx, int by, int comp) -> int {
+      int kk = k, x = bx, yy = by;
+      if (x < 0) { kk = kA; x = 3; } else if (yy < 0) { kk = kB; yy = 3; }
+      if (kk < 0) return 0;
+      return st[kk].mvd[yy * 4 + x][comp];
+    };
+    auto read_mvd = [&] (int bx, int by, int comp) -> int {        // UEG3, signedValFlag 1, uCoff 9 (9.3.2.3, 9.3.3.1.1.7)
+      const int base = comp ? 47 : 40;
+      const int sum = abs_mvd (bx - 1, by, comp) + abs_mvd (bx, by - 1, comp);
+      int inc = sum < 3 ? 0 : sum > 32 ? 2 : 1;
+      if (!cb.decode (base + inc)) return 0;
+      int v = 1;
+      inc = 3;
+      while (v < 9 && cb.decode (base + inc)) { v++; if (inc < 6) inc++; }
+      if (v == 9) {
+        int kk = 3;
+        while (cb.bypass()) { v += 1 << kk; kk++; if (kk > 24) { cb.err = true; break; } }
+        while (kk--) v += cb.bypass() << kk;
+      }
+      return cb.bypass() ? -v : v;
+    };
+    if (mbt <= 2) {
+      const int np = mbt == 0 ? 1 : 2;
+      int ref[2];
+      for (int i = 0; i < np; i++) {
+        const int bx = mbt == 2 ? i * 2 : 0, by = mbt == 1 ? i * 2 : 0;
+        ref[i] = read_ref (bx, by);
+        if (ref[i] >= nref) { fail ("ref_idx out of range"); return false; }
+        for (int q = 0; q < 4; q++) {
+          const bool in = mbt == 0 || (mbt == 1 ? (q >> 1) == i : (q & 1) == i);
+          if (in) { s.ref[q] = (int8_t)ref[i]; m.ref_idx[q] = (int8_t)ref[i]; }
+        }
+      }
+      for (int i = 0; i < np; i++) {
+        int bx = 0, by = 0, bw = 4, bh = 4, shape = 0;
+        if (mbt == 1) { bh = 2; by = i * 2; shape = 1 + i; } else if (mbt == 2) { bw = 2; bx = i * 2; shape = 3 + i; }
+        int px, py;
+        predict_mv (k, sid, filled, bx, by, bw, ref[i], shape, px, py);
+        const int dx = read_mvd (bx, by, 0), dy = read_mvd (bx, by, 1);
+        y.mvd[by * 4 + bx][0] = (int16_t)dx; y.mvd[by * 4 + bx][1] = (int16_t)dy; y.ref_idx[i] = (int8_t)ref[i];
+        fill_part (bx, by, bw, bh, px + dx, py + dy, dx, dy, filled);
+      }
+    } else {
+      int sub[4], ref[4] = {0, 0, 0, 0};
+      for (int q = 0; q < 4; q++) {                       // sub_mb_type, Table 9-37
+        if (cb.decode (21)) sub[q] = 0;
+        else if (!cb.decode (22)) sub[q] = 1;
+        else sub[q] = cb.decode (23) ? 2 : 3;
+        m.sub_type[q] = (uint8_t) (1 << sub[q]);
+      }
+      for (int q = 0; q < 4; q++) {
+        ref[q] = read_ref ((q & 1) * 2, (q >> 1) * 2);
+        if (ref[q] >= nref) { fail ("ref_idx out of range"); return false; }
+        s.ref[q] = (int8_t)ref[q]; m.ref_idx[q] = (int8_t)ref[q]; y.ref_idx[q] = (int8_t)ref[q];
+      }
+      for (int q = 0; q < 4; q++) {
+        const int qx = (q & 1) * 2, qy = (q >> 1) * 2;
+        const int nsp = sub[q] == 0 ? 1 : sub[q] == 3 ? 4 : 2;
+        for (int j = 0; j < nsp; j++) {
+          int bx = qx, by = qy, bw = 2, bh = 2;
+          if (sub[q] == 1) { bh = 1; by += j; } else if (sub[q] == 2) { bw = 1; bx += j; } else if (sub[q] == 3) { bw = bh = 1; bx += j & 1; by += j >> 1; }
+          int px, py;
+          predict_mv (k, sid, filled, bx, by, bw, ref[q], 0, px, py);
+          const int dx = read_mvd (bx, by, 0), dy = read_mvd (bx, by, 1);
+          y.mvd[by * 4 + bx][0] = (int16_t)dx; y.mvd[by * 4 + bx][1] = (int16_t)dy;
+          fill_part (bx, by, bw, bh, px + dx, py + dy, dx, dy, filled);
+        }
+      }
+    }
+  }
+  if (cb.err) return false;
+  const bool i16 = m.mb_type == LH264_MB_I16x16;
+  if (!i16) {                                           // coded_block_pattern, 9.3.2.6 / 9.3.3.1.1.4
+    auto luma_bit = [&] (int kk, int b8) -> int {     // condTermFlagN for the 8x8 block b8 of macroblock kk
+      if (kk < 0) return 0;
+      if (st[kk].pcm) return 0;
+      if (st[kk].skip) return 1;
+      return ((st[kk].cbp >> b8) & 1) ? 0 : 1;
+    };
+    int cl = 0;
+    for (int b8 = 0; b8 < 4; b8++) {
+      const int cA = (b8 & 1) ? (((cl >> (b8 - 1)) & 1) ? 0 : 1) : luma_bit (kA, b8 + 1);
+      const int cBn = (b8 & 2) ? (((cl >> (b8 - 2)) & 1) ? 0 : 1) : luma_bit (kB, b8 + 2);
+      cl |= cb.decode (73 + cA + 2 * cBn) << b8;
+    }
+    auto chroma_nz = [&] (int kk, int lvl) -> int {
+      if (kk < 0) return 0;
+      if (st[kk].pcm) return 1;
+      if (st[kk].skip) return 0;
+      return (st[kk].cbp >> 4) >= lvl;
+    };
+    int cc = 0;
+    if (cb.decode (77 + chroma_nz (kA, 1) + 2 * chroma_nz (kB, 1))) cc = cb.decode (77 + 4 + chroma_nz (kA, 2) + 2 * chroma_nz (kB, 2)) ? 2 : 1;
+    cbp = cl | (cc << 4);
+    if (!intra) {
+      bool no_sub_lt8 = true;
+      if (mbt == 3) for (int q = 0; q < 4; q++) if (m.sub_type[q] != LH264_SUB_8x8) no_sub_lt8 = false;
+      if ((cbp & 15) && P.transform_8x8 && no_sub_lt8) {
+        const int cA = kA >= 0 && st[kA].t8, cBn = kB >= 0 && st[kB].t8;
+        t8 = cb.decode (399 + cA + cBn);
+      }
+    }
+  }
+  if (cb.err) return false;
+  m.cbp = (uint8_t)cbp; s.cbp = (uint8_t)cbp;
+  if (t8) { m.flags |= LH264_MBF_T8x8; s.t8 = 1; }
+  if (intra) finalize_intra_modes (c, k, have_raw ? raw_modes : nullptr, t8, i16mode, chroma_mode);
+  int qp = qp_prev;
+  if (cbp || i16) {                                     // mb_qp_delta, 9.3.2.7 / 9.3.3.1.1.5
+    int v = 0;
+    if (cb.decode (60 + (last_dqp != 0 ? 1 : 0))) {
+      v = 1;
+      if (cb.decode (62)) { v = 2; while (cb.decode (63)) { v++; if (v > 120) { cb.err = true; break; } } }
+    }
+    const int dqp = (v & 1) ? (v + 1) >> 1 : - (v >> 1);
+    if (dqp < -26 || dqp > 25) { fail ("mb_qp_delta out of range"); return false; }
+    qp = ((qp_prev + dqp) % 52 + 52) % 52;
+    last_dqp = dqp;
+  } else last_dqp = 0;
+  set_qp (qp);
+  qp_prev = qp;
+  if (!(cbp || i16)) return !cb.err;
+
+  // ---- residual ------------------------------------------------------------------------------------------------------------
+  int lv[64];
+  const int ylist = intra ? 0 : 3;
+  if (i16) {
+    cabac_residual (cb, k, sid, 0, 0, 0, true, lv, 16);
+    for (int i = 0; i < 16; i++) if (lv[i]) {
+        const int r = kZigzag4x4[i], zb = xy2z (r & 3, r >> 2);
+        coef[zb * 16] = lev[zb * 16] = (int16_t)lv[i];
+      }
+  }
+  for (int i8 = 0; i8 < 4; i8++) {
+    if (!((cbp >> i8) & 1)) continue;
+    if (t8) {
+      const int tot = cabac_residual (cb, k, sid, 5, i8, 0, intra, lv, 64);
+      for (int j = 0; j < 4; j++) { const int z = i8 * 4 + j; m.nzc[z2y (z) * 4 + z2x (z)] = (uint8_t)tot; s.cbf |= 1u << (z2y (z) * 4 + z2x (z)); }
+      for (int i = 0; i < 64; i++) if (lv[i]) {
+          const int pos = kZigzag8x8[i];
+          lev[i8 * 64 + pos] = (int16_t)lv[i];
+          coef[i8 * 64 + pos] = (int16_t)dq8 (P, use_sl, intra ? 0 : 1, qp, pos, lv[i]);
+        }
+      continue;
+    }
+    for (int j = 0; j < 4; j++) {
+      const int z = i8 * 4 + j, bx = z2x (z), by = z2y (z);
+      const int maxc = i16 ? 15 : 16;
+      const int tot = cabac_residual (cb, k, sid, i16 ? 1 : 2, by * 4 + bx, 0, intra, lv, maxc);
+      m.nzc[by * 4 + bx] = (uint8_t)tot;
+      for (int i = 0; i < maxc; i++) if (lv[i]) {
+          const int pos = kZigzag4x4[i16 ? i + 1 : i];
+          lev[z * 16 + pos] = (int16_t)lv[i];
+          coef[z * 16 + pos] = (int16_t)dq4 (P, use_sl, ylist, qp, pos, lv[i]);
+        }
+    }
+  }
+  const int cbpc = cbp >> 4;
+  if (cbpc) {
+    for (int p = 0; p < 2; p++) {
+      cabac_residual (cb, k, sid, 3, 0, p, intra, lv, 4);
+      const int qc = m.qp_c[p];
+      const int d0 = kNormAdjust4x4[qc % 6][0] << (qc / 6);
+      for (int i = 0; i < 4; i++) if (lv[i]) {
+          lev[256 + p * 64 + i * 16] = (int16_t)lv[i];
+          coef[256 + p * 64 + i * 16] = (int16_t) (use_sl ? (lv[i] * (P.sl4[ylist + 1 + p][0] * d0)) >> 4 : lv[i] * d0);
+        }
+    }
+    if (cbpc == 2) {
+      for (int p = 0; p < 2; p++) for (int j = 0; j < 4; j++) {
+          const int tot = cabac_residual (cb, k, sid, 4, j, p, intra, lv, 15);
+          m.nzc[kChromaNzcIdx[p][j]] = (uint8_t)tot;
+          for (int i = 0; i < 15; i++) if (lv[i]) {
+              const int pos = kZigzag4x4[i + 1];
+              lev[256 + p * 64 + j * 16 + pos] = (int16_t)lv[i];
+              coef[256 + p * 64 + j * 16 + pos] = (int16_t)dq4 (P, use_sl, ylist + 1 + p, m.qp_c[p], pos, lv[i]);
+            }
+        }
+    }
+  }
+  return !cb.err;
+}
+
+bool Parser::Impl::parse_slice_data_cabac (BitReader& br, SliceCtx& c) {
+  const int n = cur->mb_w * cur->mb_h;
+  while (!br.byte_aligned()) br.u1();                   // cabac_alignment_one_bit
+  Cabac cb;
+  cb.init_contexts (c.sh->slice_type == 2 ? 0 : 1 + c.sh->cabac_init_idc, c.sh->slice_qp);
+  cb.start (rbsp.data(), rbsp.size(), br.pos);
+  int k = c.sh->first_mb, qp_prev = c.sh->slice_qp, count = 0, last_dqp = 0;
+  slice_cached_qp = 0; slice_run_before = 0;
+  const int w = cur->mb_w, sid = c.sid;
+  while (k < n) {
+    bool skip = false;
+    if (c.sh->slice_type != 2) {                        // mb_skip_flag, 9.3.3.1.1.1
+      const int kA = ((k % w) && mb_avail (k - 1, sid)) ? k - 1 : -1, kB = (k >= w && mb_avail (k - w, sid)) ? k - w : -1;
+      skip = cb.decode (11 + (kA >= 0 && !st[kA].skip) + (kB >= 0 && !st[kB].skip)) != 0;
+    }
+    if (!parse_mb_cabac (cb, c, k, qp_prev, last_dqp, skip)) { if (self->err_.empty()) fail ("CABAC error"); return false; }
+    slice_run_before = skip ? slice_run_before + 1 : 0;
+    k++; count++;
+    if (cb.terminate()) break;                          // end_of_slice_flag
+    if (cb.err) { fail ("CABAC error (ran out of data)"); return false; }
+  }
+  cur->slices[c.sid].n_mbs = count;
+  {
+    SliceSyn ss; ss.pad_bits = 0; ss.pad_value = 0; ss.transform8x8_pps = c.P->transform_8x8 ? 1 : 0; ss.cabac = 1;
+    if (cur->slice_syn.size() <= (size_t)c.sid) cur->slice_syn.resize ((size_t)c.sid + 1);
+    cur->slice_syn[c.sid] = ss;
+  }
+  return true;
+}
+
 int Parser::Impl::handle_nal (const uint8_t* nal, size_t len) {
   if (len < 1) return 0;
   const int type = nal[0] & 31, ref_idc = (nal[0] >> 5) & 3;
@@ -888,7 +1398,7 @@ int Parser::Impl::handle_nal (const uint8_t* nal, size_t len) {
     if (!parse_slice_header (br, type, ref_idc, sh)) return -1;
     if (sh.redundant_pic_cnt > 0) return 0;
     const Pps& P = pps[sh.pps_id]; const Sps& S = sps[P.sps_id];
-    if (P.cabac) { self->n_unsupported_++; fail ("CABAC streams are not supported by the host front end yet"); return -1; }
+
     const bool new_pic = !cur || sh.frame_num != first_sh.frame_num || sh.idr != first_sh.idr || sh.pps_id != first_sh.pps_id ||
                          (sh.idr && sh.idr_pic_id != first_sh.idr_pic_id) || ((sh.nal_ref_idc == 0) != (first_sh.nal_ref_idc == 0)) ||
                          sh.poc_lsb != first_sh.poc_lsb || sh.delta_poc[0] != first_sh.delta_poc[0] || sh.first_mb <= last_first_mb ||
@@ -922,7 +1432,7 @@ int Parser::Impl::handle_nal (const uint8_t* nal, size_t len) {
     }
     cur->slices.push_back (sl);
     if (sh.first_mb >= S.mb_w * S.mb_h) { fail ("first_mb_in_slice out of range"); return -1; }
-    if (!parse_slice_data_cavlc (br, c)) return -1;
+    if (P.cabac ? !parse_slice_data_cabac (br, c) : !parse_slice_data_cavlc (br, c)) return -1;
     return 0;
   }
   if (type == 10 || type == 11) finish_picture();

@@ -35,6 +35,8 @@ STREAMS = [
     ("roundtriptest/tibby8x8cavlc.264", 6),   # High profile, 8x8 transform + I8x8
     ("roundtriptest/tibbycabac.264", 4),  # CABAC-parsed records
     ("res/CI1_FT_B.264", 4),              # CIF CABAC interlace-free main profile
+    ("res/test_qcif_cabac.264", 6),       # QCIF CABAC I/P
+    ("res/CI_MW_D.264", 6),               # QCIF CABAC, multiple partitions
 ]
 
 
