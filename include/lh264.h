@@ -275,6 +275,12 @@ void  lh264_parser_destroy (lh264_parser_t* p);
 /* feed Annex-B bytes ending on a NAL boundary; flush != 0 completes the picture in progress. <0 on a parse error
  * (lh264_parser_error gives the text; pictures parsed so far stay available) */
 int   lh264_parser_feed (lh264_parser_t* p, const uint8_t* data, size_t len, int flush);
+/* a whole Annex-B file, cut into chunks and fed the way the reference's console application does (h264dec.cpp:246-272,
+ * one ISVCDecoder::DecodeFrameNoDelay per start-code-delimited chunk), flush included.  Besides the pictures this builds
+ * the recompressor's default stream (stream id 0x7fffffff, the ".pip" file itself: the input minus its slice data,
+ * decoder.cpp:658-860, au_parser.cpp:143,588, decode_slice.cpp:2974-2980), returned by lh264_parser_main_stream */
+int   lh264_parser_feed_file (lh264_parser_t* p, const uint8_t* data, size_t len);
+const uint8_t* lh264_parser_main_stream (const lh264_parser_t* p, size_t* len);
 int   lh264_parser_frame_count (const lh264_parser_t* p);
 int   lh264_parser_frame_info (const lh264_parser_t* p, int idx, lh264_frame_info_t* out);
 const lh264_mb_t*    lh264_parser_frame_mbs (const lh264_parser_t* p, int idx);

@@ -8,7 +8,7 @@ fallback: without the built library or without a GPU every compute call raises.
 from ._lib import lib, LibraryMissing, MB_DTYPE, SLICE_DTYPE, JOB_DTYPE, pic_geometry  # noqa: F401
 from .recon import ReconSession  # noqa: F401
 from .ctx import CtxSession, past_policy  # noqa: F401
-from .parse import parse_stream  # noqa: F401
+from .parse import parse_stream, parse_file  # noqa: F401
 from .coder import CoderSession  # noqa: F401
 
-__all__ = ["lib", "LibraryMissing", "ReconSession", "CtxSession", "past_policy", "parse_stream", "CoderSession", "MB_DTYPE", "SLICE_DTYPE", "JOB_DTYPE", "pic_geometry"]
+__all__ = ["lib", "LibraryMissing", "ReconSession", "CtxSession", "past_policy", "parse_stream", "parse_file", "CoderSession", "MB_DTYPE", "SLICE_DTYPE", "JOB_DTYPE", "pic_geometry"]

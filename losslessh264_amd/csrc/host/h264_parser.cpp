@@ -113,6 +113,7 @@ struct Parser::Impl {
   int persist_w = 0, persist_h = 0;
   int slice_cached_qp = 0, slice_run_before = 0;
   Symbolizer symbolizer;
+  int last_hdr_bits = -1; bool last_cabac = false;       // the slice NAL just handled: header length in bits, entropy mode
 
   explicit Impl (Parser* s) : self (s) {}
 
@@ -1432,6 +1433,7 @@ int Parser::Impl::handle_nal (const uint8_t* nal, size_t len) {
     }
     cur->slices.push_back (sl);
     if (sh.first_mb >= S.mb_w * S.mb_h) { fail ("first_mb_in_slice out of range"); return -1; }
+    last_hdr_bits = (int)br.pos; last_cabac = P.cabac;
     if (P.cabac ? !parse_slice_data_cabac (br, c) : !parse_slice_data_cavlc (br, c)) return -1;
     return 0;
   }
@@ -1468,6 +1470,88 @@ int Parser::feed (const uint8_t* d, size_t n) {
     while (end > start && d[end - 1] == 0) end--;
     if (end > start && feed_nal (d + start, end - start) < 0) rc = -1;
   }
+  return rc;
+}
+
+// ---- the recompressor's default stream ---------------------------------------------------------------------------
+void MainStreamWriter::append_byte (uint8_t x) {
+  if (!escaping_) { buffer.push_back (x); return; }
+  if (x <= 3 && esc_n_ == 2 && esc_[0] == 0 && esc_[1] == 0) {
+    const uint8_t e[4] = {0, 0, 3, x};
+    buffer.insert (buffer.end(), e, e + 4);
+    esc_n_ = 0;
+  } else if (esc_n_ == 2) {
+    buffer.push_back (esc_[0]); esc_[0] = esc_[1]; esc_[1] = x;
+  } else esc_[esc_n_++] = x;
+}
+void MainStreamWriter::emit_bit (uint32_t bit) {
+  bits_ = (bits_ << 1) | (bit & 1);
+  if (++n_bits_ == 8) { const uint8_t b = (uint8_t)bits_; bits_ = 0; n_bits_ = 0; append_byte (b); }
+}
+void MainStreamWriter::stop_escape() {
+  pad_to_byte();
+  escaping_ = false;
+  for (int i = 0; i < esc_n_; i++) buffer.push_back (esc_[i]);
+  esc_n_ = 0;
+}
+
+// What the reference leaves in the default stream for each chunk the console application hands to DecodeFrameNoDelay
+// (WelsDecodeBs decoder.cpp:658-860 for the chunk, then once more with no data): the bytes up to and including the
+// start code; then, escaped: the NAL header byte (au_parser.cpp:143), for SPS/PPS/SEI the RBSP without its trailing
+// zero bytes (au_parser.cpp:588), one zero byte per trailing zero byte (decoder.cpp:610-627), for a slice the bits of its
+// header (decode_slice.cpp:2974-2980) and, for CAVLC, a single 1 bit (decoder.cpp:837-845); zero bits up to the byte.
+int Parser::feed_file (const uint8_t* d, size_t n) {
+  int rc = 0;
+  size_t pos = 0;
+  std::vector<uint8_t> nal;
+  auto at = [&] (size_t i) -> int { return i < n ? d[i] : (i == n + 3 ? 1 : 0); };   // the application appends 00 00 00 01
+  while (pos < n) {
+    size_t i;
+    for (i = 0; i < n; i++) {
+      if (i > 0 && at (pos + i) == 0 && at (pos + i + 1) == 0 && ((at (pos + i + 2) == 0 && at (pos + i + 3) == 1) || at (pos + i + 2) == 1)) break;
+    }
+    const size_t len = i;
+    if (len < 4) { main_.append_bytes (d + pos, std::min (len, n - pos)); pos += len; continue; }
+    const uint8_t* c = d + pos;
+    pos += len;
+    // first start code prefix (DetectStartCodePrefix au_parser.cpp:64-87)
+    size_t off = 0; bool found = false;
+    for (size_t q = 0, zeros = 0; q < len; q++) {
+      if (c[q] == 0) { zeros++; continue; }
+      if (c[q] == 1 && zeros >= 2) { off = q + 1; found = true; break; }
+      zeros = 0;
+    }
+    if (!found) continue;
+    main_.append_bytes (c, off);
+    Impl::unescape (c + off, len - off, nal);
+    main_.start_escape();
+    size_t tz = 0;
+    while (tz < nal.size() && nal[nal.size() - 1 - tz] == 0) tz++;
+    bool slice_ok = false;
+    if (!nal.empty() && !(nal[0] & 0x80)) {
+      const int type = nal[0] & 31;
+      main_.append_byte (nal[0]);
+      const bool have_sps = !d_->sps.empty(), have_pps = !d_->pps.empty();
+      if (type == 6 || type == 7 || (type == 8 && have_sps)) {
+        if (nal.size() > 1 + tz) main_.append_bytes (nal.data() + 1, nal.size() - 1 - tz);
+      }
+      if ((type == 1 || type == 5 || type == 7 || type == 8) && (type == 7 || have_sps) && (type == 7 || type == 8 || have_pps)) {
+        size_t end = len;
+        while (end > off && c[end - 1] == 0) end--;
+        d_->last_hdr_bits = -1;
+        if (end > off && feed_nal (c + off, end - off) < 0) rc = -1;
+        slice_ok = (type == 1 || type == 5) && d_->last_hdr_bits >= 0;
+      }
+    }
+    for (size_t q = 0; q < tz; q++) main_.append_byte (0);
+    if (slice_ok) {
+      for (int b = 0; b < d_->last_hdr_bits; b++) main_.emit_bit ((d_->rbsp[(size_t)b >> 3] >> (7 - (b & 7))) & 1);
+      if (!d_->last_cabac) main_.emit_bit (1);
+    }
+    main_.stop_escape();
+  }
+  flush();
+  main_.pad_to_byte();
   return rc;
 }
 

@@ -115,10 +115,30 @@ struct FrameOut {
   std::vector<uint32_t> syn_off;           // mb_w*mb_h + 1 offsets
 };
 
+// The recompressor's default stream (".pip" itself, stream id 0x7fffffff): the Annex-B input minus its slice data.
+// Byte-level behaviour of the reference's BitStream (compression_stream.cpp:40-120, compression_stream.h:71-84): while
+// escaping is on, bytes pass through a two-byte window that re-inserts emulation-prevention bytes.
+class MainStreamWriter {
+ public:
+  std::vector<uint8_t> buffer;
+  void append_byte (uint8_t x);
+  void append_bytes (const uint8_t* d, size_t n) { for (size_t i = 0; i < n; i++) append_byte (d[i]); }
+  void emit_bit (uint32_t bit);
+  void start_escape() { escaping_ = true; }
+  void stop_escape();
+  void pad_to_byte() { while (n_bits_ & 7) emit_bit (0); }
+ private:
+  uint32_t bits_ = 0; int n_bits_ = 0; bool escaping_ = false; uint8_t esc_[2] = {0, 0}; int esc_n_ = 0;
+};
+
 class Parser {
  public:
   Parser();
   ~Parser();
+  // a whole Annex-B file, cut and fed the way the reference's console application does (h264dec.cpp:246-272, one
+  // DecodeFrameNoDelay per start-code-delimited chunk); also builds the recompressor's default stream, main_stream()
+  int feed_file (const uint8_t* data, size_t len);
+  const std::vector<uint8_t>& main_stream() const { return main_.buffer; }
   // feed a whole Annex-B byte stream (or a piece that ends on a NAL boundary); completed pictures are appended to frames()
   int feed (const uint8_t* data, size_t len);
   int feed_nal (const uint8_t* nal, size_t len);      // one NAL unit without start code (with emulation prevention bytes)
@@ -135,6 +155,7 @@ class Parser {
   std::vector<std::unique_ptr<FrameOut>> frames_;
   std::string err_;
   int n_unsupported_ = 0;
+  MainStreamWriter main_;
   friend struct Impl;
 };
 

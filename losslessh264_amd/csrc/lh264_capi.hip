@@ -196,6 +196,15 @@ int lh264_parser_feed (lh264_parser_t* p, const uint8_t* data, size_t len, int f
   if (flush) p->p.flush();
   return rc < 0 ? LH264_E_UNSUPPORTED : LH264_OK;
 }
+int lh264_parser_feed_file (lh264_parser_t* p, const uint8_t* data, size_t len) {
+  if (!p || (!data && len)) return LH264_E_ARG;
+  return p->p.feed_file (data, len) < 0 ? LH264_E_UNSUPPORTED : LH264_OK;
+}
+const uint8_t* lh264_parser_main_stream (const lh264_parser_t* p, size_t* len) {
+  if (!p) return nullptr;
+  if (len) *len = p->p.main_stream().size();
+  return p->p.main_stream().data();
+}
 int lh264_parser_frame_count (const lh264_parser_t* p) { return p ? (int)const_cast<lh264_parser_t*> (p)->p.frames().size() : 0; }
 static const lh264host::FrameOut* pf (const lh264_parser_t* p, int idx) {
   if (!p) return nullptr;

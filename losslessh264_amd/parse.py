@@ -10,12 +10,21 @@ class ParsedFrame:
     pass
 
 
-def parse_stream(data, strict=False):
+def parse_file(data, strict=False):
+    """A whole Annex-B file fed chunk by chunk as the reference's console application does.
+    -> (frames, error_text, main_stream): main_stream is the recompressor's default stream (the '.pip' file itself)."""
+    return parse_stream(data, strict, _file=True)
+
+
+def parse_stream(data, strict=False, _file=False):
     """-> (frames, error_text).  frames have the attributes ReconSession / CtxSession expect."""
     lib = L.lib()
     p = lib.lh264_parser_create()
     try:
-        rc = lib.lh264_parser_feed(p, bytes(data), len(data), 1)
+        if _file:
+            rc = lib.lh264_parser_feed_file(p, bytes(data), len(data))
+        else:
+            rc = lib.lh264_parser_feed(p, bytes(data), len(data), 1)
         err = lib.lh264_parser_error(p).decode()
         if rc != 0 and strict:
             raise RuntimeError("h264 parse error: " + err)
@@ -45,6 +54,10 @@ def parse_stream(data, strict=False):
             f.syn_syms = arr(ptr, cnt.value * 8, L.CTX_SYM_DTYPE) if cnt.value else np.zeros(0, L.CTX_SYM_DTYPE)
             f.syn_off = arr(lib.lh264_parser_frame_syn_offsets(p, i), (n + 1) * 4, "<u4")
             frames.append(f)
+        if _file:
+            ln = C.c_size_t(0)
+            ptr = lib.lh264_parser_main_stream(p, C.byref(ln))
+            return frames, err, (C.string_at(ptr, ln.value) if ln.value else b"")
         return frames, err
     finally:
         lib.lh264_parser_destroy(p)

@@ -16,7 +16,7 @@ class GFrame:
 
 def list_fixtures():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith(("bench_", "pip_")))
+                  if not os.path.basename(p).startswith(("bench_", "pip_", "cli_")))
 
 
 def load(name):
