@@ -290,7 +290,8 @@ const lh264_slice_t* lh264_parser_frame_slices (const lh264_parser_t* p, int idx
 const uint8_t*       lh264_parser_frame_covered (const lh264_parser_t* p, int idx);
 /* row a10: the macroblock syntax the recompressor codes beyond lh264_mb_t (the reference's DecodedMacroblock fields,
  * decoded_macroblock.h:12-34): one packed 116-byte lh264_mbsyn_t per macroblock, and per slice 4 x int32
- * {alignment bit count after the stop bit, their value, PPS transform_8x8_mode_flag, entropy_coding_mode_flag} */
+ * {alignment bit count after the stop bit, their value, PPS transform_8x8_mode_flag,
+ * flags: bit 0 entropy_coding_mode_flag, bit 1 constrained_intra_pred_flag} */
 typedef struct lh264_mbsyn {
   uint8_t  have, slice_type, t8, cbp_c, cbp_l, chroma_mode, luma16_mode, luma_qp;
   uint8_t  mb_type[4], num_ref_idx_l0[4], skip_run[4];   /* little-endian u32 / u32 / i32 (the struct is byte-packed) */
@@ -306,6 +307,16 @@ const int32_t*       lh264_parser_frame_slice_syntax (const lh264_parser_t* p, i
 const lh264_ctx_sym_t* lh264_parser_frame_syn_symbols (const lh264_parser_t* p, int idx, int* count);
 const uint32_t*      lh264_parser_frame_syn_offsets (const lh264_parser_t* p, int idx);
 const char*          lh264_parser_error (const lh264_parser_t* p);
+
+/* ---- restore direction, host side ------------------------------------------------------------
+ * The inverse of compress: the default stream (".pip") plus the tagged arithmetic-coded streams (".pip.<tag>") -> the
+ * original Annex-B bytes (what `h264dec in.pip out.264` does in the reference: decode_slice.cpp:2476-2936, decoder.cpp:658-860).
+ * tags[t] / tag_len[t] are indexed by tag id (billing.h:6-55), n_tags >= 70 to include the pad-bit tag 69; NULL = no such
+ * stream.  *out_len receives the restored size; LH264_E_ARG when out_cap is too small (then *out_len = the size needed).
+ * CAVLC streams only for now: a CABAC slice or an I_PCM macroblock gives LH264_E_UNSUPPORTED (lh264_restore_error: the text). */
+int lh264_pip_restore (const uint8_t* main_stream, size_t main_len, const uint8_t* const* tags, const size_t* tag_len, int n_tags,
+                       uint8_t* out, size_t out_cap, size_t* out_len);
+const char* lh264_restore_error (void);       /* message of the calling thread's last failed lh264_pip_restore */
 
 #define LH264_OK            0
 #define LH264_E_NODEVICE   -1

@@ -394,7 +394,7 @@ struct Parser::Impl {
     for (const auto& d : dpb) cur->dpb_ids.push_back (d.frame_id);
     {   // the row-a10 symbol lists exist for CAVLC pictures (the CABAC variant of the reference's emit code is not restated)
       bool cavlc = cur->slice_syn.size() == cur->slices.size();
-      for (const auto& ss : cur->slice_syn) cavlc = cavlc && !ss.cabac;
+      for (const auto& ss : cur->slice_syn) cavlc = cavlc && !(ss.flags & 1);
       if (cavlc) symbolizer.picture (*cur);
       else { cur->syn_off.assign ((size_t)cur->mb_w * cur->mb_h + 1, 0); cur->syn_syms.clear(); }
     }
@@ -925,7 +925,7 @@ bool Parser::Impl::parse_slice_data_cavlc (BitReader& br, SliceCtx& c) {
     ss.pad_bits = 7 - (int) (stop & 7);
     ss.pad_value = (ss.pad_bits && (stop >> 3) < rbsp.size()) ? (rbsp[stop >> 3] & ((1 << ss.pad_bits) - 1)) : 0;
     ss.transform8x8_pps = c.P->transform_8x8 ? 1 : 0;
-    ss.cabac = c.P->cabac ? 1 : 0;
+    ss.flags = (c.P->cabac ? 1 : 0) | (c.P->constrained_intra_pred ? 2 : 0);
     if (cur->slice_syn.size() <= (size_t)c.sid) cur->slice_syn.resize ((size_t)c.sid + 1);
     cur->slice_syn[c.sid] = ss;
   }
@@ -1380,7 +1380,7 @@ bool Parser::Impl::parse_slice_data_cabac (BitReader& br, SliceCtx& c) {
   }
   cur->slices[c.sid].n_mbs = count;
   {
-    SliceSyn ss; ss.pad_bits = 0; ss.pad_value = 0; ss.transform8x8_pps = c.P->transform_8x8 ? 1 : 0; ss.cabac = 1;
+    SliceSyn ss; ss.pad_bits = 0; ss.pad_value = 0; ss.transform8x8_pps = c.P->transform_8x8 ? 1 : 0; ss.flags = 1 | (c.P->constrained_intra_pred ? 2 : 0);
     if (cur->slice_syn.size() <= (size_t)c.sid) cur->slice_syn.resize ((size_t)c.sid + 1);
     cur->slice_syn[c.sid] = ss;
   }
@@ -1472,6 +1472,25 @@ int Parser::feed (const uint8_t* d, size_t n) {
   }
   return rc;
 }
+
+int Parser::parse_headers (const uint8_t* nal, size_t len, HeaderInfo& o) {
+  if (len < 1) return -1;
+  o = HeaderInfo();
+  o.nal_type = nal[0] & 31;
+  const int ref_idc = (nal[0] >> 5) & 3;
+  Impl::unescape (nal + 1, len - 1, d_->rbsp);
+  BitReader br; br.init (d_->rbsp.data(), d_->rbsp.size());
+  if (o.nal_type == 7) { d_->parse_sps (br); return 0; }
+  if (o.nal_type == 8) { d_->parse_pps (br); return 0; }
+  if (o.nal_type != 1 && o.nal_type != 5) return 0;
+  if (!d_->parse_slice_header (br, o.nal_type, ref_idc, o.sh)) return -1;
+  const Pps& P = d_->pps[o.sh.pps_id]; const Sps& S = d_->sps[P.sps_id];
+  o.is_slice = true; o.hdr_bits = (int)br.pos; o.mb_w = S.mb_w; o.mb_h = S.mb_h;
+  o.cabac = P.cabac; o.transform_8x8 = P.transform_8x8; o.constrained_intra_pred = P.constrained_intra_pred;
+  return 0;
+}
+const std::vector<uint8_t>& Parser::last_rbsp() const { return d_->rbsp; }
+void Parser::unescape (const uint8_t* d, size_t n, std::vector<uint8_t>& out) { Impl::unescape (d, n, out); }
 
 // ---- the recompressor's default stream ---------------------------------------------------------------------------
 void MainStreamWriter::append_byte (uint8_t x) {

@@ -96,7 +96,7 @@ struct MbSyn {
 };
 #pragma pack(pop)
 static_assert (sizeof (MbSyn) == 116, "MbSyn layout");
-struct SliceSyn { int32_t pad_bits, pad_value, transform8x8_pps, cabac; };   // alignment bits after the slice's stop bit (decode_slice.cpp:3133-3148)
+struct SliceSyn { int32_t pad_bits, pad_value, transform8x8_pps, flags /* bit 0 entropy_coding_mode_flag, bit 1 constrained_intra_pred_flag */; };   // alignment bits after the slice's stop bit (decode_slice.cpp:3133-3148)
 
 // one parsed picture: exactly what lh264_recon_chains / lh264_ctx_index_chains consume
 struct FrameOut {
@@ -124,6 +124,8 @@ class MainStreamWriter {
   void append_byte (uint8_t x);
   void append_bytes (const uint8_t* d, size_t n) { for (size_t i = 0; i < n; i++) append_byte (d[i]); }
   void emit_bit (uint32_t bit);
+  void emit_bits (uint32_t v, int n) { for (int i = n - 1; i >= 0; i--) emit_bit ((v >> i) & 1); }
+  int bits_in_byte() const { return n_bits_; }
   void start_escape() { escaping_ = true; }
   void stop_escape();
   void pad_to_byte() { while (n_bits_ & 7) emit_bit (0); }
@@ -138,6 +140,15 @@ class Parser {
   // a whole Annex-B file, cut and fed the way the reference's console application does (h264dec.cpp:246-272, one
   // DecodeFrameNoDelay per start-code-delimited chunk); also builds the recompressor's default stream, main_stream()
   int feed_file (const uint8_t* data, size_t len);
+  // headers only (the restore direction reads them from the default stream): SPS / PPS are remembered, for a slice NAL the
+  // header is parsed and described; no picture is started.  nal = one NAL unit without start code.  <0: not parseable
+  struct HeaderInfo {
+    int nal_type = 0; bool is_slice = false; SliceHeader sh; int hdr_bits = 0, mb_w = 0, mb_h = 0;
+    bool cabac = false, transform_8x8 = false, constrained_intra_pred = false;
+  };
+  int parse_headers (const uint8_t* nal, size_t len, HeaderInfo& out);
+  const std::vector<uint8_t>& last_rbsp() const;     // the unescaped payload of the NAL handled last
+  static void unescape (const uint8_t* d, size_t n, std::vector<uint8_t>& out);
   const std::vector<uint8_t>& main_stream() const { return main_.buffer; }
   // feed a whole Annex-B byte stream (or a piece that ends on a NAL boundary); completed pictures are appended to frames()
   int feed (const uint8_t* data, size_t len);

@@ -133,17 +133,31 @@ void Symbolizer::picture (FrameOut& f) {
       }
       int8_t* my_ipm = &ipm_[(size_t)k * 8];
       if (type == LH264_MB_I4x4 || type == LH264_MB_I8x8) {
-        // the decoder's intra-mode cache (WelsFillCacheConstrain0IntraNxN parse_mb_syn_cavlc.cpp:204-248): a neighbour counts
-        // when it lies in the same slice
+        // the decoder's intra-mode cache (WelsFillCacheConstrain0IntraNxN / ...Constrain1IntraNxN parse_mb_syn_cavlc.cpp:157-248): a
+        // neighbour counts when it lies in the same slice; with constrained_intra_pred only an I4x4 neighbour lends its modes,
+        // I16x16 / I_PCM count as DC and everything else as unavailable, and samples are available from intra neighbours only
+        // (WelsMapNxNNeighToSampleConstrain1 DS:419-438)
         int8_t cache[48];
         memset (cache, 0, sizeof (cache));
-        const bool left_av = x > 0 && k - 1 >= S.first_mb, top_av = k - w >= S.first_mb, topleft_av = x > 0 && k - w - 1 >= S.first_mb;
-        if (top_av && nxn_[k - w]) memcpy (cache + 1, &ipm_[(size_t) (k - w) * 8], 4);
-        else memset (cache + 1, top_av ? 2 : -1, 4);
-        if (left_av && nxn_[k - 1]) {
-          const int8_t* li = &ipm_[(size_t) (k - 1) * 8];
-          cache[8] = li[4]; cache[16] = li[5]; cache[24] = li[6]; cache[32] = li[3];
-        } else cache[8] = cache[16] = cache[24] = cache[32] = (int8_t) (left_av ? 2 : -1);
+        const bool cip = (X.flags & 2) != 0;
+        bool left_av = x > 0 && k - 1 >= S.first_mb, top_av = k - w >= S.first_mb, topleft_av = x > 0 && k - w - 1 >= S.first_mb;
+        const uint32_t lt = left_av ? f.mbs[k - 1].mb_type : 0, tt = top_av ? f.mbs[k - w].mb_type : 0, tlt = topleft_av ? f.mbs[k - w - 1].mb_type : 0;
+        if (!cip) {
+          if (top_av && nxn_[k - w]) memcpy (cache + 1, &ipm_[(size_t) (k - w) * 8], 4);
+          else memset (cache + 1, top_av ? 2 : -1, 4);
+          if (left_av && nxn_[k - 1]) {
+            const int8_t* li = &ipm_[(size_t) (k - 1) * 8];
+            cache[8] = li[4]; cache[16] = li[5]; cache[24] = li[6]; cache[32] = li[3];
+          } else cache[8] = cache[16] = cache[24] = cache[32] = (int8_t) (left_av ? 2 : -1);
+        } else {
+          if (top_av && tt == LH264_MB_I4x4) memcpy (cache + 1, &ipm_[(size_t) (k - w) * 8], 4);
+          else memset (cache + 1, (tt == LH264_MB_I16x16 || tt == LH264_MB_IPCM) ? 2 : -1, 4);
+          if (left_av && lt == LH264_MB_I4x4) {
+            const int8_t* li = &ipm_[(size_t) (k - 1) * 8];
+            cache[8] = li[4]; cache[16] = li[5]; cache[24] = li[6]; cache[32] = li[3];
+          } else cache[8] = cache[16] = cache[24] = cache[32] = (int8_t) ((lt == LH264_MB_I16x16 || lt == LH264_MB_IPCM) ? 2 : -1);
+          left_av = left_av && (lt & LH264_MB_INTRA); top_av = top_av && (tt & LH264_MB_INTRA); topleft_av = topleft_av && (tlt & LH264_MB_INTRA);
+        }
         if (type == LH264_MB_I4x4) {                 // DS:2301-2318
           int sample_av[30];
           memset (sample_av, 0, sizeof (sample_av));

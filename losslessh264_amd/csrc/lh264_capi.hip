@@ -8,6 +8,7 @@
 #include <string>
 #include "../../include/lh264.h"
 #include "host/h264_parser.h"
+#include "host/pip_restore.h"
 
 namespace lh264 {
 __global__ void recon_chain_kernel (const lh264_frame_job_t* jobs, const int32_t* chain_first, int n_chains, int line_bytes);
@@ -196,6 +197,18 @@ int lh264_parser_feed (lh264_parser_t* p, const uint8_t* data, size_t len, int f
   if (flush) p->p.flush();
   return rc < 0 ? LH264_E_UNSUPPORTED : LH264_OK;
 }
+static thread_local std::string g_restore_err;
+int lh264_pip_restore (const uint8_t* main_stream, size_t main_len, const uint8_t* const* tags, const size_t* tag_len, int n_tags,
+                       uint8_t* out, size_t out_cap, size_t* out_len) {
+  if (!main_stream || !tags || !tag_len || !out_len || n_tags < 0) return LH264_E_ARG;
+  std::vector<uint8_t> o;
+  if (lh264host::pip_restore (main_stream, main_len, tags, tag_len, n_tags, o, g_restore_err) < 0) return LH264_E_UNSUPPORTED;
+  *out_len = o.size();
+  if (o.size() > out_cap || (!out && o.size())) { g_restore_err = "output buffer too small"; return LH264_E_ARG; }
+  if (o.size()) memcpy (out, o.data(), o.size());
+  return LH264_OK;
+}
+const char* lh264_restore_error (void) { return g_restore_err.c_str(); }
 int lh264_parser_feed_file (lh264_parser_t* p, const uint8_t* data, size_t len) {
   if (!p || (!data && len)) return LH264_E_ARG;
   return p->p.feed_file (data, len) < 0 ? LH264_E_UNSUPPORTED : LH264_OK;

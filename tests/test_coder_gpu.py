@@ -51,3 +51,34 @@ def test_replicas_are_identical_and_rerun_is_stable():
     ref = {int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")}
     for c in range(5):
         assert coder.tags(c) == ref
+
+
+# ---- whole streams: compress on the device, compare with the reference CLI's files, restore, compare with the input -----
+CLI = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(golden_io.GOLDEN_DIR, "cli_*.npz")))
+CLI_CAVLC = [n for n in CLI if "cabac" not in n.lower()]
+
+
+def test_whole_stream_compress_equals_reference_cli_and_round_trips():
+    """.264 -> (default stream from the host front end, tagged streams from the HIP coder) == the files the reference's console
+    application writes; and those restore (csrc/host/pip_restore.cpp) to the input, bit for bit"""
+    import losslessh264_amd as lh
+    datas, streams, mains = [], [], []
+    for name in CLI_CAVLC:
+        data = open(os.path.join(golden_io.GOLDEN_DIR, "streams", name), "rb").read()
+        frames, err, main = lh.parse_file(data)
+        assert err == ""
+        datas.append(data); streams.append(frames); mains.append(main)
+    ctx = lh.CtxSession(streams)
+    ctx.run()
+    coder = lh.CoderSession(ctx, hash_cap=1 << 17, out_cap=1 << 17)
+    coder.run()
+    ctx.synchronize()
+    for c, name in enumerate(CLI_CAVLC):
+        z = np.load(os.path.join(golden_io.GOLDEN_DIR, "cli_" + name + ".npz"))
+        ref = {int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")}
+        got = coder.tags(c)
+        assert mains[c] == z["main"].tobytes(), name
+        assert sorted(got) == sorted(ref), (name, sorted(got), sorted(ref))
+        for t in sorted(ref):
+            assert got[t] == ref[t], "%s tag %d: %d bytes, reference %d" % (name, t, len(got[t]), len(ref[t]))
+        assert lh.restore(mains[c], got) == datas[c], name

@@ -35,3 +35,57 @@ def test_feed_file_gives_the_same_pictures_as_feed():
     assert len(a) == len(b)
     for f, g in zip(a, b):
         assert np.array_equal(f.mbs, g.mbs) and np.array_equal(f.coeffs, g.coeffs) and np.array_equal(f.syn, g.syn)
+
+
+# ---- restore direction (row f2): reference-written files -> the original bytes ------------------------------------------
+def _is_cabac(name):
+    frames, _ = lh.parse_stream(open(os.path.join(STREAMS, name), "rb").read())
+    return any(int(f.slice_syn[0, 3]) & 1 for f in frames)
+
+
+CAVLC = [n for n in CLI if "cabac" not in n.lower()]
+
+
+@pytest.mark.parametrize("name", CAVLC)
+def test_restore_reference_files_gives_original_stream(name):
+    """the files the reference's compressor wrote (main + every tag) decode back to the input, bit for bit"""
+    main, tags = cli_fixture(name)
+    out = lh.restore(main, tags)
+    assert out == open(os.path.join(STREAMS, name), "rb").read()
+
+
+def test_restore_reports_what_it_cannot_do():
+    main, tags = cli_fixture("test_qcif_cabac.264")
+    with pytest.raises(RuntimeError, match="CABAC"):
+        lh.restore(main, tags)
+    main, tags = cli_fixture("SVA_BA2_D.264")
+    t2 = dict(tags)
+    del t2[19]
+    with pytest.raises(RuntimeError, match="missing"):
+        lh.restore(main, t2)
+
+
+def test_restore_survives_corrupt_input():
+    """damaged tag streams or a damaged default stream must end in an error or in different bytes, never in a crash"""
+    rng = np.random.default_rng(11)
+    main, tags = cli_fixture("SVA_BA1_B.264")
+    orig = open(os.path.join(STREAMS, "SVA_BA1_B.264"), "rb").read()
+    for trial in range(12):
+        t2 = {t: bytearray(b) for t, b in tags.items()}
+        m2 = bytearray(main)
+        if trial % 3 == 2:
+            for pos in rng.integers(5, len(m2), 3):
+                m2[pos] = int(rng.integers(0, 256))
+        else:
+            for t in list(t2)[trial % 5::5]:
+                b = t2[t]
+                for pos in rng.integers(0, len(b), max(1, len(b) // 50)):
+                    b[pos] = int(rng.integers(0, 256))
+                if trial % 2:
+                    del b[len(b) // 2:]
+        try:
+            out = lh.restore(bytes(m2), {t: bytes(b) for t, b in t2.items()})
+            assert isinstance(out, bytes)
+        except RuntimeError:
+            pass
+    assert lh.restore(main, tags) == orig
