@@ -354,14 +354,29 @@ int orc_coder_picture (orc_coder_t* c, int mb_w, int mb_h, int frame_num, const 
           memset (cache, 0, sizeof (cache));
           /* GetNeighborAvailMbType: a neighbour counts when it belongs to the same slice (consecutive macroblocks, no FMO) */
           (void)avail;
-          const int left_av = x > 0 && k - 1 >= S->first_mb, top_av = k - mb_w >= S->first_mb,
-                    topleft_av = x > 0 && k - mb_w - 1 >= S->first_mb;
-          if (top_av && c->mbclass[k - mb_w]) memcpy (cache + 1, c->ipm + (size_t) (k - mb_w) * 8, 4);
-          else memset (cache + 1, top_av ? 2 : -1, 4);
-          if (left_av && c->mbclass[k - 1]) {
-            const int8_t* li = c->ipm + (size_t) (k - 1) * 8;
-            cache[8] = li[4]; cache[16] = li[5]; cache[24] = li[6]; cache[32] = li[3];
-          } else cache[8] = cache[16] = cache[24] = cache[32] = (int8_t) (left_av ? 2 : -1);
+          int left_av = x > 0 && k - 1 >= S->first_mb, top_av = k - mb_w >= S->first_mb,
+              topleft_av = x > 0 && k - mb_w - 1 >= S->first_mb;
+          if (!((S->transform8x8_pps >> 1) & 1)) {
+            if (top_av && c->mbclass[k - mb_w]) memcpy (cache + 1, c->ipm + (size_t) (k - mb_w) * 8, 4);
+            else memset (cache + 1, top_av ? 2 : -1, 4);
+            if (left_av && c->mbclass[k - 1]) {
+              const int8_t* li = c->ipm + (size_t) (k - 1) * 8;
+              cache[8] = li[4]; cache[16] = li[5]; cache[24] = li[6]; cache[32] = li[3];
+            } else cache[8] = cache[16] = cache[24] = cache[32] = (int8_t) (left_av ? 2 : -1);
+          } else {
+            /* constrained_intra_pred: WelsFillCacheConstrain1IntraNxN parse_mb_syn_cavlc.cpp:157-202 (only an I4x4 neighbour lends
+             * its modes; I16x16 / I_PCM count as DC, the rest as unavailable) and WelsMapNxNNeighToSampleConstrain1
+             * decode_slice.cpp:419-438 (samples from intra neighbours only) */
+            const unsigned lt = left_av ? mb_types[k - 1] : 0, tt = top_av ? mb_types[k - mb_w] : 0, tlt = topleft_av ? mb_types[k - mb_w - 1] : 0;
+            const unsigned intra = MBT_I4x4 | MBT_I16x16 | MBT_I8x8 | MBT_IPCM;
+            if (top_av && tt == MBT_I4x4) memcpy (cache + 1, c->ipm + (size_t) (k - mb_w) * 8, 4);
+            else memset (cache + 1, (tt == MBT_I16x16 || tt == MBT_IPCM) ? 2 : -1, 4);
+            if (left_av && lt == MBT_I4x4) {
+              const int8_t* li = c->ipm + (size_t) (k - 1) * 8;
+              cache[8] = li[4]; cache[16] = li[5]; cache[24] = li[6]; cache[32] = li[3];
+            } else cache[8] = cache[16] = cache[24] = cache[32] = (int8_t) ((lt == MBT_I16x16 || lt == MBT_IPCM) ? 2 : -1);
+            left_av = left_av && (lt & intra); top_av = top_av && (tt & intra); topleft_av = topleft_av && (tlt & intra);
+          }
           if (R->mb_type == MBT_I4x4) {
             int sample_av[30];
             memset (sample_av, 0, sizeof (sample_av));
@@ -425,7 +440,7 @@ int orc_coder_picture (orc_coder_t* c, int mb_w, int mb_h, int frame_num, const 
           int no_sub_lt8 = 1;
           if (R->mb_type == MBT_8x8 || R->mb_type == MBT_8x8_REF0) for (int i = 0; i < 4; i++) no_sub_lt8 &= R->sub_type[i] == SUB_8x8;
           const int is_inter = (R->mb_type & (MBT_16x16 | MBT_16x8 | MBT_8x16 | MBT_8x8 | MBT_8x8_REF0 | MBT_SKIP)) != 0;
-          if ((((R->mb_type >= MBT_16x16 && R->mb_type <= MBT_8x16) || no_sub_lt8) && is_inter && R->cbp_l > 0 && S->transform8x8_pps))
+          if ((((R->mb_type >= MBT_16x16 && R->mb_type <= MBT_8x16) || no_sub_lt8) && is_inter && R->cbp_l > 0 && (S->transform8x8_pps & 1)))
             emit_bit (c, T_T8, R->t8, store_get (&c->st, TB_T8, (uint32_t) (mbc * 128 + R->luma_qp)));
         }
         /* coefficients: the a8 restatement supplies (kind, prior index, value) in emission order */

@@ -20,3 +20,32 @@ def test_parser_survives_damaged_streams(tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0, (r.stdout.decode()[-2000:], r.stderr.decode()[-6000:])
     assert b"cases=" in r.stdout
+
+
+def test_restore_survives_damaged_files(tmp_path):
+    """the restore direction and the default-stream writer under ASan/UBSan: clean files of the reference's console application
+    restore exactly; damaged, truncated and missing tag streams are rejected or decoded to something else without memory errors"""
+    import numpy as np
+    exe = str(tmp_path / "restore_stress")
+    host = os.path.join(ROOT, "losslessh264_amd", "csrc", "host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "restore_stress.cpp"),
+                           os.path.join(host, "h264_parser.cpp"), os.path.join(host, "pip_symbols.cpp"),
+                           os.path.join(host, "pip_restore.cpp"), "-o", exe])
+    bases = []
+    for name in ("SVA_BA2_D.264", "SVA_BA1_B.264", "test_vd_1d.264", "CI_MW_D.264", "tibby8x8cavlc.264"):
+        z = np.load(os.path.join(ROOT, "tests", "golden", "cli_" + name + ".npz"))
+        base = str(tmp_path / name.rsplit(".", 1)[0])
+        with open(base + ".264", "wb") as f:
+            f.write(open(os.path.join(ROOT, "tests", "golden", "streams", name), "rb").read())
+        with open(base + ".pip", "wb") as f:
+            f.write(z["main"].tobytes())
+        for k in z.files:
+            if k.startswith("tag_"):
+                with open(base + ".pip." + k[4:], "wb") as f:
+                    f.write(z[k].tobytes())
+        bases.append(base)
+    r = subprocess.run([exe] + bases, capture_output=True, timeout=900,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, (r.stdout.decode()[-2000:], r.stderr.decode()[-6000:])
+    assert b"cases=" in r.stdout
