@@ -97,7 +97,7 @@ def main():
     data = open(os.path.join(ROOT, "tests", "golden", "streams", "BA_MW_D.264"), "rb").read()
     stream_bytes = len(data)
     assert stream_bytes == golden_io.load.stream_bytes
-    frames, perr = lh.parse_stream(data)
+    frames, perr, main_stream = lh.parse_file(data)     # main_stream: the recompressor's default stream (the .pip file itself)
     assert perr == "" and len(frames) == len(ref_frames)
     for f, g in zip(frames, ref_frames):
         f.crc_fin, f.syms = g.crc_fin, g.syms
@@ -172,6 +172,25 @@ def main():
         coder_info = {"ms": c_ms, "MB_per_s": args.streams * stream_bytes / c_ms / 1e3, "coded_bytes_per_stream": coded,
                       "reference_tagged_bytes": 52742, "ratio_tagged": coded / stream_bytes,
                       "note": "one wave per stream; throughput scales with the stream count (300 MB/s at 4096 streams)"}
+        # the whole compressed representation (default stream + tagged streams) against the reference's, and back again
+        tags = coder.tags(args.streams - 1)
+        assert len(main_stream) + coded == 53739, "compressed size differs from the reference's 53,739 bytes"
+        roundtrip = {"ratio": (len(main_stream) + coded) / stream_bytes, "reference_ratio": 53739 / 55885,
+                     "roundtrip_ok": lh.restore(main_stream, tags) == data}
+        assert roundtrip["roundtrip_ok"], "restore(compress(stream)) differs from the stream"
+        if rank == 0 and world == 1 and not args.no_cpu:
+            # host stages on this box's cores (rows f1 / f2): the front end (parse + default stream + syntax symbols) and the
+            # restore direction (adaptive decode + CAVLC writer), one stream per thread, bounded to a few seconds each
+            ncpu = min(16, len(os.sched_getaffinity(0)))      # a one-GPU box's CPU share is 16 cores
+            nb = 8 * ncpu
+            pt, _ = lh.parse_batch_time([data] * nb, ncpu)
+            t0 = time.perf_counter()
+            outs = lh.restore_batch([(main_stream, tags)] * nb, ncpu)
+            rt = time.perf_counter() - t0
+            assert all(o == data for o in outs)
+            roundtrip["host_stages"] = {"threads": ncpu, "streams": nb, "front_end_MB_per_s": nb * stream_bytes / pt / 1e6,
+                                        "restore_MB_per_s": nb * stream_bytes / rt / 1e6}
+        coder_info["roundtrip"] = roundtrip
         del coder
 
     if rank == 0:

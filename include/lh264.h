@@ -318,6 +318,20 @@ int lh264_pip_restore (const uint8_t* main_stream, size_t main_len, const uint8_
                        uint8_t* out, size_t out_cap, size_t* out_len);
 const char* lh264_restore_error (void);       /* message of the calling thread's last failed lh264_pip_restore */
 
+/* ---- batches of independent streams on the host cores (streams are independent, one thread each) --
+ * lh264_parse_batch: n Annex-B files -> n parsers (lh264_parser_feed_file each), `threads` worker threads (0 = one per
+ * hardware thread).  parsers_out[i] is always a valid handle to destroy; its error text tells whether the stream parsed.
+ * lh264_pip_restore_batch: n restores as lh264_pip_restore, item by item; item.status receives the return code. */
+int lh264_parse_batch (const uint8_t* const* data, const size_t* len, int n, int threads, lh264_parser_t** parsers_out);
+typedef struct lh264_restore_item {
+  const uint8_t* main_stream; size_t main_len;
+  const uint8_t* const* tags; const size_t* tag_len; int32_t n_tags;
+  int32_t status;                 /* out: LH264_OK / LH264_E_*                       */
+  uint8_t* out; size_t out_cap;   /* caller's buffer                                 */
+  size_t out_len;                 /* out: restored size (or the size needed)         */
+} lh264_restore_item_t;
+int lh264_pip_restore_batch (lh264_restore_item_t* items, int n, int threads);
+
 #define LH264_OK            0
 #define LH264_E_NODEVICE   -1
 #define LH264_E_ARG        -2

@@ -11,6 +11,31 @@
 
 namespace lh264host {
 
+namespace {
+struct ZeroCache {                  // per thread: up to kKeep released blocks, matched by exact size
+  enum { kKeep = 512 };
+  struct E { void* p; size_t bytes; } e[kKeep];
+  int n = 0;
+  ~ZeroCache() { for (int i = 0; i < n; i++) free (e[i].p); }
+};
+thread_local ZeroCache g_zero_cache;
+}
+void* zerobuf_get (size_t bytes) {
+  ZeroCache& c = g_zero_cache;
+  for (int i = c.n - 1; i >= 0; i--) if (c.e[i].bytes == bytes) {
+      void* p = c.e[i].p;
+      c.e[i] = c.e[--c.n];
+      memset (p, 0, bytes);
+      return p;
+    }
+  return calloc (1, bytes);
+}
+void zerobuf_put (void* p, size_t bytes) {
+  ZeroCache& c = g_zero_cache;
+  if (c.n < ZeroCache::kKeep && bytes <= (size_t)8 << 20) { c.e[c.n].p = p; c.e[c.n].bytes = bytes; c.n++; }
+  else free (p);
+}
+
 bool BitReader::more_rbsp_data() const {
   if (pos >= nbits) return false;
   // find the last set bit of the payload (the rbsp stop bit)
@@ -413,7 +438,7 @@ struct Parser::Impl {
     cur->crop_w = S.mb_w * 16 - 2 * (S.crop_l + S.crop_r); cur->crop_h = S.mb_h * 16 - 2 * (S.crop_t + S.crop_b);
     const size_t n = (size_t)S.mb_w * S.mb_h;
     cur->mbs.assign (n, lh264_mb_t()); memset (cur->mbs.data(), 0, n * sizeof (lh264_mb_t));
-    cur->coeffs.assign (n * 384, 0); cur->levels.assign (n * 384, 0); cur->covered.assign (n, 0);
+    cur->coeffs.assign_zero ((size_t)n * 384); cur->levels.assign_zero ((size_t)n * 384); cur->covered.assign (n, 0);
     cur->syn.assign (n, MbSyn()); memset (cur->syn.data(), 0, n * sizeof (MbSyn));
     if (persist_w != S.mb_w || persist_h != S.mb_h) {       // the decoder re-allocates (zeroed) on a resolution change
       persist_w = S.mb_w; persist_h = S.mb_h;
@@ -425,6 +450,20 @@ struct Parser::Impl {
   }
 
   // ---- CAVLC residual block (9.2) ------------------------------------------------------------------------------------
+  struct TokLut { uint16_t t[5][1024]; };          // total_coeff << 8 | trailing_ones << 4 | length, by the next 10 bits
+  static const TokLut& tok_lut() {
+    static const TokLut lut = [] {
+      TokLut L; memset (&L, 0, sizeof (L));
+      for (int tab = 0; tab < 5; tab++) if (tab != 3) for (int i = 0; i < kCoeffTokenCount[tab]; i++) {
+            const VlcTok& t = kCoeffToken[tab][i];
+            if (t.len == 0 || t.len > 10) continue;
+            const uint32_t lo = (uint32_t)t.code << (10 - t.len);
+            for (uint32_t q = 0; q < (1u << (10 - t.len)); q++) L.t[tab][lo + q] = (uint16_t) (t.total_coeff << 8 | t.trailing_ones << 4 | t.len);
+          }
+      return L;
+    }();
+    return lut;
+  }
   // returns total_coeff, writes levels in scan order positions start..; -1 on error
   int residual_block (BitReader& br, int nC, int max_coeff, int* level /*[16] in scan order (index = position in the block's scan)*/) {
     const int tab = nC < 0 ? 4 : nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3;
@@ -434,7 +473,10 @@ struct Parser::Impl {
       if (v == 3) { total = 0; t1 = 0; } else { total = (v >> 2) + 1; t1 = v & 3; }
     } else {
       const uint32_t bits = br.peek (16);
-      for (int i = 0; i < kCoeffTokenCount[tab]; i++) {
+      const TokLut& L = tok_lut();
+      const uint16_t e = L.t[tab][bits >> 6];           // codes of up to 10 bits resolve in one look-up
+      if (e) { total = e >> 8; t1 = (e >> 4) & 3; br.skip (e & 15); }
+      else for (int i = 0; i < kCoeffTokenCount[tab]; i++) {
         const VlcTok& t = kCoeffToken[tab][i];
         if ((bits >> (16 - t.len)) == t.code) { total = t.total_coeff; t1 = t.trailing_ones; br.skip (t.len); break; }
       }
@@ -448,7 +490,11 @@ struct Parser::Impl {
     for (int i = 0; i < total; i++) {
       if (i < t1) { lv[i] = br.u1() ? -1 : 1; continue; }
       int prefix = 0;
-      while (!br.u1()) { if (br.err || ++prefix > 32) return -1; }
+      {
+        const uint32_t w = br.peek (32);
+        if (w) { prefix = __builtin_clz (w); br.skip (prefix + 1); if (br.err) return -1; }
+        else { while (!br.u1()) { if (br.err || ++prefix > 32) return -1; } }
+      }
       int code = std::min (15, prefix) << suffix_len;
       int ssize = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
       if (ssize > 0) code += (int)br.u (ssize);

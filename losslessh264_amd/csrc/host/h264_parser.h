@@ -5,6 +5,8 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include <map>
 #include <memory>
 #include <string>
@@ -15,18 +17,34 @@ namespace lh264host {
 
 struct BitReader {
   const uint8_t* p = nullptr;
-  size_t nbits = 0, pos = 0;
+  size_t nbits = 0, pos = 0, nbytes = 0;
   bool err = false;
-  void init (const uint8_t* d, size_t bytes) { p = d; nbits = bytes * 8; pos = 0; err = false; }
-  inline uint32_t u1() { if (pos >= nbits) { err = true; return 0; } uint32_t b = (p[pos >> 3] >> (7 - (pos & 7))) & 1; pos++; return b; }
-  inline uint32_t u (int n) { uint32_t v = 0; while (n-- > 0) v = (v << 1) | u1(); return v; }
-  inline uint32_t peek (int n) const {       // n <= 24, zero-extended past the end
-    uint32_t v = 0; size_t q = pos;
-    for (int i = 0; i < n; i++, q++) v = (v << 1) | (q < nbits ? ((p[q >> 3] >> (7 - (q & 7))) & 1) : 0);
-    return v;
+  void init (const uint8_t* d, size_t bytes) { p = d; nbytes = bytes; nbits = bytes * 8; pos = 0; err = false; }
+  // the next n <= 32 bits, zero-extended past the end
+  inline uint32_t peek (int n) const {
+    const size_t b = pos >> 3;
+    uint64_t v;
+    if (b + 8 <= nbytes) { memcpy (&v, p + b, 8); v = __builtin_bswap64 (v); }
+    else { v = 0; for (size_t i = 0; i < 8; i++) v = (v << 8) | (b + i < nbytes ? p[b + i] : 0); }
+    return n ? (uint32_t) ((v << (pos & 7)) >> (64 - n)) : 0;
   }
   inline void skip (int n) { pos += n; if (pos > nbits) err = true; }
-  uint32_t ue() { int z = 0; while (!u1()) { if (err || ++z > 32) { err = true; return 0; } } return z == 0 ? 0 : ((1u << z) - 1 + u (z)); }
+  inline uint32_t u1() { if (pos >= nbits) { err = true; return 0; } uint32_t b = (p[pos >> 3] >> (7 - (pos & 7))) & 1; pos++; return b; }
+  inline uint32_t u (int n) {             // n <= 32
+    if (pos + (size_t)n > nbits) { err = true; pos = nbits; return 0; }
+    const uint32_t v = peek (n); pos += n; return v;
+  }
+  uint32_t ue() {
+    const uint32_t w = peek (32);
+    if (w >> 16) {                        // at most 15 leading zeros: the whole code lies in the window
+      const int z = __builtin_clz (w);
+      const int len = 2 * z + 1;
+      if (pos + (size_t)len > nbits) { err = true; pos = nbits; return 0; }
+      pos += len;
+      return (w >> (32 - len)) - 1;
+    }
+    int z = 0; while (!u1()) { if (err || ++z > 32) { err = true; return 0; } } return z == 0 ? 0 : ((1u << z) - 1 + u (z));
+  }
   int32_t se() { uint32_t k = ue(); return (k & 1) ? (int32_t) ((k + 1) >> 1) : - (int32_t) (k >> 1); }
   bool byte_aligned() const { return (pos & 7) == 0; }
   bool more_rbsp_data() const;
@@ -98,12 +116,34 @@ struct MbSyn {
 static_assert (sizeof (MbSyn) == 116, "MbSyn layout");
 struct SliceSyn { int32_t pad_bits, pad_value, transform8x8_pps, flags /* bit 0 entropy_coding_mode_flag, bit 1 constrained_intra_pred_flag */; };   // alignment bits after the slice's stop bit (decode_slice.cpp:3133-3148)
 
+// zero-initialised array for the per-picture coefficient planes (768 bytes per macroblock, ~300x the size of the bitstream
+// they come from).  Released blocks go to a small per-thread cache and are cleared on reuse: handing them back to the C library
+// means fresh page faults for the next picture, and in a process that parses several streams side by side those serialise
+// on the address-space lock (measured: 8 threads 1.8x one thread before, see DESIGN.md host front end).
+void* zerobuf_get (size_t bytes);
+void zerobuf_put (void* p, size_t bytes);
+template <typename T> class ZeroBuf {
+ public:
+  ZeroBuf() {}
+  ~ZeroBuf() { if (p_) zerobuf_put (p_, n_ * sizeof (T)); }
+  ZeroBuf (const ZeroBuf&) = delete;
+  ZeroBuf& operator= (const ZeroBuf&) = delete;
+  void assign_zero (size_t n) { if (p_) zerobuf_put (p_, n_ * sizeof (T)); p_ = n ? (T*)zerobuf_get (n * sizeof (T)) : nullptr; n_ = p_ ? n : 0; }
+  T* data() { return p_; }
+  const T* data() const { return p_; }
+  size_t size() const { return n_; }
+  T& operator[] (size_t i) { return p_[i]; }
+  const T& operator[] (size_t i) const { return p_[i]; }
+ private:
+  T* p_ = nullptr; size_t n_ = 0;
+};
+
 // one parsed picture: exactly what lh264_recon_chains / lh264_ctx_index_chains consume
 struct FrameOut {
   int id = 0, mb_w = 0, mb_h = 0, frame_num = 0, crop_w = 0, crop_h = 0, crop_x = 0, crop_y = 0;
   bool idr = false, is_ref = false, complete = false;
   std::vector<lh264_mb_t> mbs;
-  std::vector<int16_t> coeffs, levels;
+  ZeroBuf<int16_t> coeffs, levels;
   std::vector<lh264_slice_t> slices;
   std::vector<int> ref_ids;             // ids of the pictures this one references (its job's ref slots)
   std::vector<int> dpb_ids;             // ids still marked 'used for reference' once this picture is done (others may be freed)

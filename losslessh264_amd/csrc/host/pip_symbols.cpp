@@ -57,7 +57,9 @@ void Symbolizer::update_frame (int frame_id) {
 void Symbolizer::picture (FrameOut& f) {
   const int w = f.mb_w, n = f.mb_w * f.mb_h;
   if ((int)ipm_.size() != n * 8) { ipm_.assign ((size_t)n * 8, 0); nxn_.assign (n, 0); }
-  std::vector<std::vector<lh264_ctx_sym_t>> per_mb (n);
+  // symbols in coding order; a macroblock's run is [start, start + cnt)
+  std::vector<lh264_ctx_sym_t>& flat = flat_; flat.clear();
+  start_.assign (n, 0); cnt_.assign (n, 0);
   for (size_t si = 0; si < f.slices.size(); si++) {
     const lh264_slice_t& S = f.slices[si];
     const SliceSyn& X = f.slice_syn[si];
@@ -75,7 +77,9 @@ void Symbolizer::picture (FrameOut& f) {
     const int end = S.first_mb + S.n_mbs;
     int skip_state = -1, mb_in_slice = 0, cached_qp = 0, last_nonzero_dqp = 0;
     for (int k = S.first_mb; k < end && k < n; k++, mb_in_slice++) {
-      Out o = {per_mb[k]};
+      Out o = {flat};
+      start_[k] = (uint32_t)flat.size();
+      struct Close { std::vector<lh264_ctx_sym_t>& v; uint32_t& s; uint32_t& c; ~Close() { c = (uint32_t)v.size() - s; } } close_run = {flat, start_[k], cnt_[k]};
       const int x = k % w;
       const Cell* nl = (x > 0 && cur[k - 1].initialized) ? &cur[k - 1] : nullptr;              // Neighbors::init MM:9-44
       const Cell* na = (k >= w && cur[k - w].initialized) ? &cur[k - w] : nullptr;
@@ -212,7 +216,7 @@ void Symbolizer::picture (FrameOut& f) {
         if (((type >= LH264_MB_P16x16 && type <= LH264_MB_P8x16) || no_sub_lt8) && is_inter && R.cbp_l > 0 && X.transform8x8_pps)
           o.put (LH264_SYM_BIT, LH264_TB_T8, (uint32_t) (mbc * 128 + R.luma_qp), R.t8, TAG_T8);
       }
-      { lh264_ctx_sym_t s; s.prior = 0; s.value = 0; s.kind = LH264_SYM_SPLICE; s.pad = 0; per_mb[k].push_back (s); }
+      { lh264_ctx_sym_t s; s.prior = 0; s.value = 0; s.kind = LH264_SYM_SPLICE; s.pad = 0; flat.push_back (s); }
       // the image entry, DS:3098-3109
       Cell e;
       e.initialized = 1; e.cbp_c = R.cbp_c; e.cbp_l = R.cbp_l; e.chroma_mode = R.chroma_mode; e.luma16_mode = R.luma16_mode;
@@ -223,13 +227,16 @@ void Symbolizer::picture (FrameOut& f) {
       cur[k] = e;
     }
     // the alignment bits after the slice's stop bit go to the pad-byte tag, DS:3133-3148
-    if (X.pad_bits && end - 1 < n && end - 1 >= S.first_mb) { Out o = {per_mb[end - 1]}; o.raw (X.pad_value, X.pad_bits, TAG_PADBYTE); }
+    if (X.pad_bits && end - 1 < n && end - 1 >= S.first_mb && start_[end - 1] + cnt_[end - 1] == flat.size()) {
+      Out o = {flat}; o.raw (X.pad_value, X.pad_bits, TAG_PADBYTE); cnt_[end - 1]++;
+    }
   }
   f.syn_off.assign ((size_t)n + 1, 0);
   f.syn_syms.clear();
+  f.syn_syms.reserve (flat.size());
   for (int k = 0; k < n; k++) {
     f.syn_off[k] = (uint32_t)f.syn_syms.size();
-    f.syn_syms.insert (f.syn_syms.end(), per_mb[k].begin(), per_mb[k].end());
+    f.syn_syms.insert (f.syn_syms.end(), flat.begin() + start_[k], flat.begin() + start_[k] + cnt_[k]);
   }
   f.syn_off[n] = (uint32_t)f.syn_syms.size();
 }

@@ -28,6 +28,7 @@ class Symbolizer {
   int img_w_ = 0, img_h_ = 0, cur_ = 0, last_frame_id_ = 0;
   std::vector<int8_t> ipm_;           // the decoder's pIntraPredMode[mb][0..6] (raw modes of the bottom row / right column)
   std::vector<uint8_t> nxn_;          // macroblock is I4x4 / I8x8
+  std::vector<lh264_ctx_sym_t> flat_; std::vector<uint32_t> start_, cnt_;   // scratch of picture()
   void update_frame (int frame_id);
 };
 

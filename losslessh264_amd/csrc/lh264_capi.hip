@@ -6,6 +6,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <atomic>
+#include <thread>
+#include <vector>
 #include "../../include/lh264.h"
 #include "host/h264_parser.h"
 #include "host/pip_restore.h"
@@ -32,6 +35,18 @@ static int fail (int code, const char* what, hipError_t e = hipSuccess) {
   return code;
 }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail (LH264_E_HIP, #call, e_); } while (0)
+
+template <typename F> static void run_parallel (int n, int threads, F&& fn) {
+  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n;
+  std::atomic<int> next (0);
+  auto worker = [&] () { for (;;) { const int i = next.fetch_add (1); if (i >= n) break; fn (i); } };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; t++) pool.emplace_back (worker);
+  worker();
+  for (auto& t : pool) t.join();
+}
 
 extern "C" {
 
@@ -209,6 +224,20 @@ int lh264_pip_restore (const uint8_t* main_stream, size_t main_len, const uint8_
   return LH264_OK;
 }
 const char* lh264_restore_error (void) { return g_restore_err.c_str(); }
+int lh264_parse_batch (const uint8_t* const* data, const size_t* len, int n, int threads, lh264_parser_t** parsers_out) {
+  if (!data || !len || !parsers_out || n < 0) return LH264_E_ARG;
+  for (int i = 0; i < n; i++) parsers_out[i] = new lh264_parser();
+  run_parallel (n, threads, [&] (int i) { if (data[i] || !len[i]) parsers_out[i]->p.feed_file (data[i], len[i]); });
+  return LH264_OK;
+}
+int lh264_pip_restore_batch (lh264_restore_item_t* items, int n, int threads) {
+  if (!items || n < 0) return LH264_E_ARG;
+  run_parallel (n, threads, [&] (int i) {
+    lh264_restore_item_t& it = items[i];
+    it.status = lh264_pip_restore (it.main_stream, it.main_len, it.tags, it.tag_len, it.n_tags, it.out, it.out_cap, &it.out_len);
+  });
+  return LH264_OK;
+}
 int lh264_parser_feed_file (lh264_parser_t* p, const uint8_t* data, size_t len) {
   if (!p || (!data && len)) return LH264_E_ARG;
   return p->p.feed_file (data, len) < 0 ? LH264_E_UNSUPPORTED : LH264_OK;

@@ -16,6 +16,25 @@ def parse_file(data, strict=False):
     return parse_stream(data, strict, _file=True)
 
 
+def parse_batch_time(datas, threads=0):
+    """parse a batch of Annex-B files on host threads (C ABI lh264_parse_batch) and throw the records away:
+    -> (seconds, pictures parsed).  For the host-throughput line of bench.py."""
+    import time
+    lib = L.lib()
+    n = len(datas)
+    ptrs = (C.c_char_p * n)(*[bytes(d) for d in datas])
+    lens = (C.c_size_t * n)(*[len(d) for d in datas])
+    outs = (C.c_void_p * n)()
+    t0 = time.perf_counter()
+    L.check(lib.lh264_parse_batch(ptrs, lens, n, threads, outs))
+    dt = time.perf_counter() - t0
+    pics = 0
+    for i in range(n):
+        pics += lib.lh264_parser_frame_count(outs[i])
+        lib.lh264_parser_destroy(outs[i])
+    return dt, pics
+
+
 def parse_stream(data, strict=False, _file=False):
     """-> (frames, error_text).  frames have the attributes ReconSession / CtxSession expect."""
     lib = L.lib()

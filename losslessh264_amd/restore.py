@@ -28,3 +28,40 @@ def restore(main, tags, size_hint=None):
             continue
         break
     raise RuntimeError("restore failed: " + lib.lh264_restore_error().decode())
+
+
+RESTORE_ITEM = None
+
+
+def _item_type():
+    global RESTORE_ITEM
+    if RESTORE_ITEM is None:
+        class Item(C.Structure):
+            _fields_ = [("main_stream", C.c_char_p), ("main_len", C.c_size_t), ("tags", C.POINTER(C.c_char_p)), ("tag_len", C.POINTER(C.c_size_t)),
+                        ("n_tags", C.c_int32), ("status", C.c_int32), ("out", C.c_void_p), ("out_cap", C.c_size_t), ("out_len", C.c_size_t)]
+        RESTORE_ITEM = Item
+    return RESTORE_ITEM
+
+
+def restore_batch(items, threads=0, out_cap=None):
+    """items: list of (main bytes, {tag: bytes}) -> list of restored byte strings (None where a restore failed), one host
+    thread per stream (C ABI lh264_pip_restore_batch)."""
+    lib = L.lib()
+    Item = _item_type()
+    arr = (Item * len(items))()
+    keep = []
+    for i, (main, tags) in enumerate(items):
+        ptrs = (C.c_char_p * N_TAG_IDS)()
+        lens = (C.c_size_t * N_TAG_IDS)()
+        for t, b in tags.items():
+            if 0 <= t < N_TAG_IDS:
+                ptrs[t] = bytes(b)
+                lens[t] = len(b)
+        cap = out_cap or (4 * (len(main) + sum(len(b) for b in tags.values())) + 4096)
+        buf = C.create_string_buffer(cap)
+        keep.append((ptrs, lens, buf))
+        it = arr[i]
+        it.main_stream, it.main_len, it.tags, it.tag_len, it.n_tags = bytes(main), len(main), ptrs, lens, N_TAG_IDS
+        it.out, it.out_cap = C.addressof(buf), cap
+    L.check(lib.lh264_pip_restore_batch(C.byref(arr), len(items), threads))
+    return [keep[i][2].raw[:arr[i].out_len] if arr[i].status == 0 else None for i in range(len(items))]

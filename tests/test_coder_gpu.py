@@ -82,3 +82,28 @@ def test_whole_stream_compress_equals_reference_cli_and_round_trips():
         for t in sorted(ref):
             assert got[t] == ref[t], "%s tag %d: %d bytes, reference %d" % (name, t, len(got[t]), len(ref[t]))
         assert lh.restore(mains[c], got) == datas[c], name
+
+
+def test_command_line_compress_and_restore(tmp_path):
+    """`python -m losslessh264_amd in.264 out.pip out.yuv` writes the reference console application's files (names and bytes), the
+    YUV dump has the SHA-1 of the reference's decoder test, and `... out.pip back.264` gives the input back"""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    name = "SVA_BA1_B.264"
+    src = os.path.join(golden_io.GOLDEN_DIR, "streams", name)
+    pip, yuv, back = str(tmp_path / "out.pip"), str(tmp_path / "out.yuv"), str(tmp_path / "back.264")
+    root = os.path.dirname(golden_io.GOLDEN_DIR.rstrip("/")).rsplit("/tests", 1)[0]
+    env = dict(os.environ, PYTHONPATH=root)
+    subprocess.check_call([sys.executable, "-m", "losslessh264_amd", src, pip, yuv], env=env, cwd=root)
+    z = np.load(os.path.join(golden_io.GOLDEN_DIR, "cli_" + name + ".npz"))
+    assert open(pip, "rb").read() == z["main"].tobytes()
+    written = sorted(int(p.rsplit(".", 1)[1]) for p in glob.glob(pip + ".*"))
+    assert written == sorted(int(k[4:]) for k in z.files if k.startswith("tag_"))
+    for t in written:
+        assert open("%s.%d" % (pip, t), "rb").read() == z["tag_%d" % t].tobytes(), t
+    sha = json.load(open(os.path.join(golden_io.GOLDEN_DIR, "decoder_sha1.json")))
+    assert hashlib.sha1(open(yuv, "rb").read()).hexdigest() == sha[name]
+    subprocess.check_call([sys.executable, "-m", "losslessh264_amd", pip, back], env=env, cwd=root)
+    assert open(back, "rb").read() == open(src, "rb").read()
