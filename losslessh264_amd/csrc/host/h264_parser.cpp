@@ -417,10 +417,8 @@ struct Parser::Impl {
     if (first_sh.nal_ref_idc) { mark_reference (first_sh, *csps); cur->is_ref = true; prev_ref_frame_num = had_mmco5 ? 0 : first_sh.frame_num; }
     had_mmco5 = false;
     for (const auto& d : dpb) cur->dpb_ids.push_back (d.frame_id);
-    {   // the row-a10 symbol lists exist for CAVLC pictures (the CABAC variant of the reference's emit code is not restated)
-      bool cavlc = cur->slice_syn.size() == cur->slices.size();
-      for (const auto& ss : cur->slice_syn) cavlc = cavlc && !(ss.flags & 1);
-      if (cavlc) symbolizer.picture (*cur);
+    {   // the row-a10 symbol lists (every slice of the picture must have been parsed to its end)
+      if (cur->slice_syn.size() == cur->slices.size()) symbolizer.picture (*cur);
       else { cur->syn_off.assign ((size_t)cur->mb_w * cur->mb_h + 1, 0); cur->syn_syms.clear(); }
     }
     cur->complete = true;
@@ -1081,6 +1079,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
   };
   MbSyn& y = cur->syn[k];
   memset (&y, 0, sizeof (y));
+  if (c.sh->slice_type == 0) persist_chroma[k] = 0;           // WelsDecodeMbCabacPSlice resets pChromaPredMode (decode_slice.cpp:1174)
   if (is_skip) {                                        // P_Skip
     m.mb_type = LH264_MB_SKIP; s.type_class = 3; s.skip = 1;
     for (int i = 0; i < 4; i++) { s.ref[i] = 0; m.ref_idx[i] = 0; }
@@ -1095,7 +1094,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
     return true;
   }
   y.have = 1; y.slice_type = (uint8_t)sh.slice_type; y.num_ref_idx_l0 = (uint32_t)sh.num_ref_idx_l0;
-  y.skip_run = slice_run_before; y.last_mb_qp = qp_prev;
+  y.skip_run = slice_run_before ? 1 : 0; y.last_mb_qp = qp_prev;     // CABAC: the reference's run counter never passes 1 (decode_slice.cpp:1186,2205-2238)
   struct SynDone {
     Impl* d; MbSyn& y; lh264_mb_t& m; int k;
     ~SynDone() {
@@ -1426,7 +1425,11 @@ bool Parser::Impl::parse_slice_data_cabac (BitReader& br, SliceCtx& c) {
   }
   cur->slices[c.sid].n_mbs = count;
   {
-    SliceSyn ss; ss.pad_bits = 0; ss.pad_value = 0; ss.transform8x8_pps = c.P->transform_8x8 ? 1 : 0; ss.flags = 1 | (c.P->constrained_intra_pred ? 2 : 0);
+    // what the reference sends to the pad-bit tag for a CABAC slice (decode_slice.cpp:3133-3148): InitCabacDecEngineFromBS leaves
+    // iLeftBits = 0, so always 7 bits, taken from the last byte of its bit buffer = the byte holding the rbsp stop bit
+    // (DecInitBits bit_stream.cpp:72-90 with the size ParseNalHeader computes, au_parser.cpp:420-421)
+    SliceSyn ss; ss.pad_bits = 7; ss.pad_value = 0; ss.transform8x8_pps = c.P->transform_8x8 ? 1 : 0; ss.flags = 1 | (c.P->constrained_intra_pred ? 2 : 0);
+    if (!rbsp.empty()) ss.pad_value = rbsp.back() & 0x7f;
     if (cur->slice_syn.size() <= (size_t)c.sid) cur->slice_syn.resize ((size_t)c.sid + 1);
     cur->slice_syn[c.sid] = ss;
   }

@@ -73,7 +73,7 @@ void Symbolizer::picture (FrameOut& f) {
     }
     std::vector<Cell>& cur = img_[cur_];
     std::vector<Cell>& last = img_[1 - cur_];
-    const bool is_p = S.slice_type == 0;
+    const bool is_p = S.slice_type == 0, cabac = (X.flags & 1) != 0;
     const int end = S.first_mb + S.n_mbs;
     int skip_state = -1, mb_in_slice = 0, cached_qp = 0, last_nonzero_dqp = 0;
     for (int k = S.first_mb; k < end && k < n; k++, mb_in_slice++) {
@@ -86,7 +86,9 @@ void Symbolizer::picture (FrameOut& f) {
       const Cell* np = (prior_valid && last[k].initialized) ? &last[k] : nullptr;
       const bool write_skip_run = skip_state == -1;
       int mb_skip_run = 0;
-      if (is_p) {                                    // WelsDecodeMbCavlcPSlice DS:3894-3915
+      if (is_p && cabac) {                           // CABAC: a skip flag per macroblock; the run is written every time, DS:1186,2208-2210
+        mb_skip_run = f.mbs[k].mb_type == LH264_MB_SKIP ? 1 : 0;
+      } else if (is_p) {                             // WelsDecodeMbCavlcPSlice DS:3894-3915
         if (skip_state == -1) { int run = 0; while (k + run < end && f.mbs[k + run].mb_type == LH264_MB_SKIP) run++; skip_state = run; }
         mb_skip_run = skip_state;
         skip_state--;                                // a coded macroblock leaves -1: the next one reads a new run

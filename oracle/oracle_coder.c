@@ -290,7 +290,11 @@ int orc_coder_picture (orc_coder_t* c, int mb_w, int mb_h, int frame_num, const 
       const int skipped = is_p && type == MBT_SKIP;
       /* WelsDecodeMbCavlcPSlice :3894-3915: how the run counter moves */
       int mb_skip_run = 0;
-      if (is_p) {
+      if (is_p && ((S->transform8x8_pps >> 2) & 1)) {
+        /* CABAC (WelsDecodeMbCabacPSlice :1164-1200, :2208-2210): a skip flag per macroblock; the "run" is 0 or 1 and is written
+         * for every macroblock (write_skip_run is forced below by leaving skip_state at -1) */
+        mb_skip_run = skipped ? 1 : 0;
+      } else if (is_p) {
         if (skip_state == -1) {       /* mb_skip_run read here: the number of skipped macroblocks from this one on */
           int run = 0;
           while (k + run < S->first_mb + S->n_mbs && mb_types[k + run] == MBT_SKIP) run++;

@@ -34,7 +34,7 @@ typedef struct orc_slice_info {
   int32_t first_mb, n_mbs;
   int32_t slice_type;        /* 0 P, 2 I (eSliceType) */
   int32_t pad_bits, pad_value; /* bits left in the slice's last byte after its last macroblock, and their value */
-  int32_t transform8x8_pps;  /* bit 0: PPS transform_8x8_mode_flag, bit 1: PPS constrained_intra_pred_flag */
+  int32_t transform8x8_pps;  /* bit 0: PPS transform_8x8_mode_flag, bit 1: constrained_intra_pred_flag, bit 2: entropy_coding_mode_flag */
 } orc_slice_info_t;
 
 orc_coder_t* orc_coder_new (int keep_trace);

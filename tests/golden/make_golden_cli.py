@@ -22,6 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 def main():
     cli = os.path.join(ROOT, "oracle", "_ref", "h264dec")
     streams = sorted(glob.glob(os.path.join(HERE, "streams", "*")))
+    if len(sys.argv) > 1:                              # only the named streams
+        streams = [s for s in streams if os.path.basename(s) in sys.argv[1:]]
     tmp = tempfile.mkdtemp(prefix="lh264_cli_")
     running = []
     todo = list(streams)

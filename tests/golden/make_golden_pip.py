@@ -31,6 +31,8 @@ STREAMS = [
     ("res/BA_MW_D.264", 30),              # config #2 seed stream
     ("roundtriptest/tibby8x8cavlc.264", 5),   # 8x8 transform, I8x8
     ("res/CI_MW_D.264", 12),              # constrained_intra_pred: the other variant of the intra-mode cache
+    ("res/test_qcif_cabac.264", 8),       # CABAC I/P (config #5 family): skip flags instead of skip runs
+    ("roundtriptest/tibbycabac.264", 4),  # CABAC with the 8x8 transform
 ]
 
 
@@ -64,14 +66,14 @@ def main():
         # per slice: first_mb, n_mbs, slice_type, pad bit count, pad bits, PPS transform_8x8_mode_flag (bit 0)
         out["slices"] = np.array([[int(s["first_mb"]), int(s["n_mbs"]), int(s["slice_type"]), int(e[0]), int(e[1]), int(e[2])]
                                   for f in frames for s, e in zip(f.slices, f.slice_extra)], dtype=np.int32)
-        # bit 1 of the last column: the PPS's constrained_intra_pred_flag (a fact of the bitstream, read with the product's
-        # header parser; the dump does not carry it)
+        # bits 1 and 2 of the last column: the PPS's constrained_intra_pred_flag and entropy_coding_mode_flag (facts of the
+        # bitstream, read with the product's header parser; the dump does not carry them)
         sys.path.insert(0, ROOT)
         import losslessh264_amd as lh
         pf, _ = lh.parse_stream(open(os.path.join(REF, stream), "rb").read())
-        cip = np.array([(int(x) >> 1) & 1 for f in pf[:len(frames)] for x in f.slice_syn[:, 3]], dtype=np.int32)
-        assert len(cip) == len(out["slices"])
-        out["slices"][:, 5] |= cip << 1
+        fl = np.array([int(x) for f in pf[:len(frames)] for x in f.slice_syn[:, 3]], dtype=np.int32)
+        assert len(fl) == len(out["slices"])
+        out["slices"][:, 5] |= (fl & 2) | ((fl & 1) << 2)       # bit 1 constrained_intra_pred_flag, bit 2 entropy_coding_mode_flag
         for t, b in tags.items():
             if t != 0x7fffffff:
                 out["tag_%d" % t] = np.frombuffer(b, dtype=np.uint8)

@@ -63,7 +63,7 @@ def test_whole_stream_compress_equals_reference_cli_and_round_trips():
     application writes; and those restore (csrc/host/pip_restore.cpp) to the input, bit for bit"""
     import losslessh264_amd as lh
     datas, streams, mains = [], [], []
-    for name in CLI_CAVLC:
+    for name in CLI:
         data = open(os.path.join(golden_io.GOLDEN_DIR, "streams", name), "rb").read()
         frames, err, main = lh.parse_file(data)
         assert err == ""
@@ -73,7 +73,7 @@ def test_whole_stream_compress_equals_reference_cli_and_round_trips():
     coder = lh.CoderSession(ctx, hash_cap=1 << 17, out_cap=1 << 17)
     coder.run()
     ctx.synchronize()
-    for c, name in enumerate(CLI_CAVLC):
+    for c, name in enumerate(CLI):
         z = np.load(os.path.join(golden_io.GOLDEN_DIR, "cli_" + name + ".npz"))
         ref = {int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")}
         got = coder.tags(c)
@@ -81,7 +81,8 @@ def test_whole_stream_compress_equals_reference_cli_and_round_trips():
         assert sorted(got) == sorted(ref), (name, sorted(got), sorted(ref))
         for t in sorted(ref):
             assert got[t] == ref[t], "%s tag %d: %d bytes, reference %d" % (name, t, len(got[t]), len(ref[t]))
-        assert lh.restore(mains[c], got) == datas[c], name
+        if name in CLI_CAVLC:              # (the restore direction has no CABAC writer yet)
+            assert lh.restore(mains[c], got) == datas[c], name
 
 
 def test_command_line_compress_and_restore(tmp_path):

@@ -131,6 +131,7 @@ def test_syntax_records_match_reference(name):
         ref_sl = z["slices"][s0:s0 + nsl, 3:6].copy()
         ref_sl[:, 2] &= 1              # bit 1 of the fixture column = constrained_intra_pred_flag (make_golden_pip.py)
         assert np.array_equal(ref_sl, f.slice_syn[:, :3]), (name, i)
-        assert np.array_equal(z["slices"][s0:s0 + nsl, 5] >> 1, (f.slice_syn[:, 3] >> 1) & 1)
+        assert np.array_equal((z["slices"][s0:s0 + nsl, 5] >> 1) & 1, (f.slice_syn[:, 3] >> 1) & 1)
+        assert np.array_equal((z["slices"][s0:s0 + nsl, 5] >> 2) & 1, f.slice_syn[:, 3] & 1)
         mb0 += n
         s0 += nsl
