@@ -7,6 +7,7 @@
 #include "h264_parser.h"
 #include "h264_tables.h"
 #include "h264_vlc_tables.h"
+#include "h264_cabac_tables.h"
 
 namespace lh264host {
 namespace {
@@ -86,6 +87,69 @@ class PriorStore {
   size_t used_ = 0;
 };
 
+// ---- CABAC arithmetic encoding engine, ITU-T H.264 9.3.4.2 (the reference borrows its encoder's: encoder/core/src/set_mb_syn_cabac.cpp) --
+struct CabacEnc {
+  std::vector<uint8_t> bytes; uint32_t acc = 0; int nacc = 0;
+  uint32_t low = 0, range = 510; int outstanding = 0; bool first = true;
+  uint8_t state[460];
+  void init (int col, int qp) {
+    bytes.clear(); acc = 0; nacc = 0; low = 0; range = 510; outstanding = 0; first = true;
+    qp = std::min (51, std::max (0, qp));
+    for (int i = 0; i < 460; i++) {
+      const int m = kCabacInit[i][col][0], n = kCabacInit[i][col][1];
+      const int pre = std::min (126, std::max (1, ((m * qp) >> 4) + n));
+      state[i] = pre <= 63 ? (uint8_t) ((63 - pre) << 1) : (uint8_t) (((pre - 64) << 1) | 1);
+    }
+  }
+  inline void write_bit (int b) { acc = (acc << 1) | (uint32_t) (b & 1); if (++nacc == 8) { bytes.push_back ((uint8_t)acc); acc = 0; nacc = 0; } }
+  inline void put (int b) {                          // PutBit, 9.3.4.2 figure 9-9
+    if (first) first = false; else write_bit (b);
+    while (outstanding > 0) { write_bit (1 - b); outstanding--; }
+  }
+  inline void renorm() {
+    while (range < 256) {
+      if (low < 256) put (0);
+      else if (low >= 512) { low -= 512; put (1); }
+      else { low -= 256; outstanding++; }
+      range <<= 1; low <<= 1;
+    }
+  }
+  inline void encode (int ctx, int bin) {
+    uint8_t& s = state[ctx];
+    const int st = s >> 1; int mps = s & 1;
+    const uint32_t lps = kCabacRangeLps[st][(range >> 6) & 3];
+    range -= lps;
+    if ((bin & 1) != mps) {
+      low += range; range = lps;
+      if (st == 0) mps = !mps;
+      s = (uint8_t) ((kCabacNextLps[st] << 1) | mps);
+    } else s = (uint8_t) ((kCabacNextMps[st] << 1) | mps);
+    renorm();
+  }
+  inline void bypass (int bin) {
+    low <<= 1;
+    if (bin & 1) low += range;
+    if (low >= 1024) { put (1); low -= 1024; }
+    else if (low < 512) put (0);
+    else { low -= 512; outstanding++; }
+  }
+  inline void terminate (int bin) {
+    range -= 2;
+    if (bin) {
+      low += range;
+      range = 2; renorm();                           // EncodeFlush
+      put ((low >> 9) & 1);
+      write_bit ((low >> 8) & 1); write_bit (1);       // ((low >> 7) & 3) | 1: the last bit is the rbsp stop bit
+      while (nacc) write_bit (0);
+    } else renorm();
+  }
+};
+const uint8_t kSig8x8[63] = {0, 1, 2, 3, 4, 5, 5, 4, 4, 3, 3, 4, 4, 4, 5, 5, 4, 4, 4, 4, 3, 3, 6, 7, 7, 7, 8, 9, 10, 9, 8, 7, 7, 6, 11, 12, 13, 11, 6, 7, 8, 9,
+                             14, 10, 9, 8, 6, 11, 12, 13, 11, 6, 9, 14, 10, 9, 11, 12, 13, 11, 14, 10, 12};      // Table 9-43
+const uint8_t kLast8x8[63] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3,
+                              4, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8};
+const int kCatCbf[5] = {0, 4, 8, 12, 16}, kCatMap[5] = {0, 15, 29, 44, 47}, kCatAbs[5] = {0, 10, 20, 30, 39};
+
 inline int z2x (int z) { return (z & 1) | ((z >> 2) & 1) << 1; }
 inline int z2y (int z) { return ((z >> 1) & 1) | ((z >> 3) & 1) << 1; }
 const uint8_t kScan8[16] = {9, 10, 17, 18, 11, 12, 19, 20, 25, 26, 33, 34, 27, 28, 35, 36};
@@ -121,6 +185,8 @@ struct Cell {                         // what the model remembers of a macrobloc
 };
 struct WState {                       // what the CAVLC writer must know of the macroblocks around (9.2.1, 8.3.1.1)
   int32_t slice = -1; uint32_t mb_type = 0; uint8_t type_class = 0; int8_t ipm[16]; uint8_t nzc[24];
+  // CABAC context selection (9.3.3.1.1)
+  uint8_t skip = 0, t8 = 0, cbp = 0, chroma_pred = 0; int8_t ref[4]; uint8_t mvd[16][2]; uint32_t cbf = 0;
 };
 struct MbDec {                        // one decoded macroblock
   uint32_t type = 0; int cbp_c = 0, cbp_l = 0, luma_qp = 0, num_ref = 0, chroma_mode = 0, luma16_mode = 0, t8 = 0;
@@ -238,6 +304,9 @@ class Restorer {
   int pred_intra_mode (int k, int bx, int by, int w, int sid, bool cip) const;
   void write_residual_block (const int* lv, int maxc, int nC, int& total_out);
   void write_mb (const Parser::HeaderInfo& H, int k, const MbDec& m, int& qp_prev);
+  CabacEnc ce_;
+  void cabac_residual (int k, int cat, int blk, int plane, bool cur_intra, const int* lv, int maxc);
+  void write_mb_cabac (const Parser::HeaderInfo& H, int k, const MbDec* m /* null: P_Skip */, int& qp_prev, int& last_dqp);
 };
 
 // FreqImage::updateFrame DM:119-166
@@ -513,6 +582,301 @@ void Restorer::write_mb (const Parser::HeaderInfo& H, int k, const MbDec& m, int
   }
 }
 
+// ---- CABAC macroblock layer writer: 7.3.5 with the binarisations and context selection of 9.3.2 / 9.3.3, the mirror image of
+// the front end's parse_mb_cabac (csrc/host/h264_parser.cpp) -----------------------------------------------------------------
+void Restorer::cabac_residual (int k, int cat, int blk, int plane, bool cur_intra, const int* lv, int maxc) {
+  const int w = img_w_, sid = sid_;
+  WState& s = ws_[k];
+  int last_nz = -1, n_sig = 0;
+  for (int i = 0; i < maxc; i++) if (lv[i]) { last_nz = i; n_sig++; }
+  if (cat != 5) {                                          // coded_block_flag, 9.3.3.1.1.9
+    int bit, bitA, bitB; int kA = k, kB = k;
+    if (cat == 0) { bit = bitA = bitB = 16; kA = -2; kB = -2; }
+    else if (cat == 3) { bit = bitA = bitB = 17 + plane; kA = -2; kB = -2; }
+    else if (cat == 4) {
+      const int cx = blk & 1, cy = blk >> 1;
+      bit = 19 + plane * 4 + blk;
+      if (cx == 0) { kA = -2; bitA = 19 + plane * 4 + cy * 2 + 1; } else bitA = bit - 1;
+      if (cy == 0) { kB = -2; bitB = 19 + plane * 4 + 2 + cx; } else bitB = bit - 2;
+    } else {
+      const int bx = blk & 3, by = blk >> 2;
+      bit = blk;
+      if (bx == 0) { kA = -2; bitA = by * 4 + 3; } else bitA = blk - 1;
+      if (by == 0) { kB = -2; bitB = 12 + bx; } else bitB = blk - 4;
+    }
+    if (kA == -2) kA = ((k % w) && ws_[k - 1].slice == sid) ? k - 1 : -1;
+    if (kB == -2) kB = (k >= w && ws_[k - w].slice == sid) ? k - w : -1;
+    const int cA = kA < 0 ? (cur_intra ? 1 : 0) : (int) ((ws_[kA].cbf >> bitA) & 1);
+    const int cBf = kB < 0 ? (cur_intra ? 1 : 0) : (int) ((ws_[kB].cbf >> bitB) & 1);
+    ce_.encode (85 + kCatCbf[cat] + cA + 2 * cBf, n_sig != 0);
+    if (!n_sig) return;
+    s.cbf |= 1u << bit;
+  }
+  const int sig_base = cat == 5 ? 402 : 105 + kCatMap[cat], last_base = cat == 5 ? 417 : 166 + kCatMap[cat];
+  const int abs_base = cat == 5 ? 426 : 227 + kCatAbs[cat];
+  for (int i = 0; i < maxc - 1; i++) {
+    const int inc_s = cat == 5 ? kSig8x8[i] : cat == 3 ? std::min (i, 2) : i;
+    const int inc_l = cat == 5 ? kLast8x8[i] : cat == 3 ? std::min (i, 2) : i;
+    const int sig = lv[i] != 0;
+    ce_.encode (sig_base + inc_s, sig);
+    if (sig) {
+      ce_.encode (last_base + inc_l, i == last_nz);
+      if (i == last_nz) break;
+    }
+  }
+  int num_eq1 = 0, num_gt1 = 0;
+  for (int i = maxc - 1; i >= 0; i--) {
+    if (!lv[i]) continue;
+    const int mag = std::abs (lv[i]), v = mag - 1;
+    int inc = num_gt1 ? 0 : std::min (4, 1 + num_eq1);
+    ce_.encode (abs_base + inc, v > 0);
+    if (v > 0) {
+      inc = 5 + std::min (4 - (cat == 3 ? 1 : 0), num_gt1);
+      int cnt = 1;
+      while (cnt < 14) { const int bin = v > cnt; ce_.encode (abs_base + inc, bin); if (!bin) break; cnt++; }
+      if (v >= 14) {                                         // Exp-Golomb order 0 suffix, bypass coded
+        int rem = v - 14, kk = 0;
+        while (rem >= (1 << kk)) { ce_.bypass (1); rem -= 1 << kk; kk++; }
+        ce_.bypass (0);
+        while (kk--) ce_.bypass ((rem >> kk) & 1);
+      }
+    }
+    ce_.bypass (lv[i] < 0);
+    if (mag == 1) num_eq1++; else num_gt1++;
+  }
+}
+
+void Restorer::write_mb_cabac (const Parser::HeaderInfo& H, int k, const MbDec* mp, int& qp_prev, int& last_dqp) {
+  const int w = H.mb_w, sid = sid_;
+  const bool is_p = H.sh.slice_type == 0;
+  WState& s = ws_[k];
+  const int kA = ((k % w) && ws_[k - 1].slice == sid) ? k - 1 : -1, kB = (k >= w && ws_[k - w].slice == sid) ? k - w : -1;
+  if (is_p) ce_.encode (11 + (kA >= 0 && !ws_[kA].skip) + (kB >= 0 && !ws_[kB].skip), mp == nullptr);     // mb_skip_flag
+  s.slice = sid; memset (s.nzc, 0, 24); for (int i = 0; i < 16; i++) { s.ipm[i] = 2; s.mvd[i][0] = s.mvd[i][1] = 0; }
+  s.skip = 0; s.t8 = 0; s.cbp = 0; s.chroma_pred = 0; s.cbf = 0;
+  for (int i = 0; i < 4; i++) s.ref[i] = -1;
+  if (!mp) {
+    s.mb_type = LH264_MB_SKIP; s.type_class = 3; s.skip = 1;
+    for (int i = 0; i < 4; i++) s.ref[i] = 0;
+    last_dqp = 0;
+    return;
+  }
+  const MbDec& m = *mp;
+  const uint32_t type = m.type;
+  s.mb_type = type;
+  const bool intra = (type & LH264_MB_INTRA) != 0;
+  const bool i16 = type == LH264_MB_I16x16;
+  const int cbp = m.cbp_l | (m.cbp_c << 4);
+  auto i_type = [&] (bool islice, int mbt) {               // 9.3.2.5, Table 9-36
+    const int ctx0 = islice ? 3 + (kA >= 0 && ws_[kA].type_class != 1) + (kB >= 0 && ws_[kB].type_class != 1) : 17;
+    if (mbt == 0) { ce_.encode (ctx0, 0); return; }
+    ce_.encode (ctx0, 1);
+    ce_.terminate (0);
+    const int v = mbt - 1, pm = v & 3, chroma = (v >> 2) % 3, luma = v >= 12;
+    const int base = islice ? 3 : 17;
+    ce_.encode (base + (islice ? 3 : 1), luma);
+    ce_.encode (base + (islice ? 4 : 2), chroma != 0);
+    if (chroma) ce_.encode (base + (islice ? 5 : 2), chroma == 2);
+    ce_.encode (base + (islice ? 6 : 3), pm >> 1);
+    ce_.encode (base + (islice ? 7 : 3), pm & 1);
+  };
+  auto t8_flag = [&] (int v) { ce_.encode (399 + (kA >= 0 && ws_[kA].t8) + (kB >= 0 && ws_[kB].t8), v); };
+  bool t8 = false;
+  if (intra) {
+    int mbt = 0;
+    if (i16) {
+      static const int kRaw16[7] = {0, 1, 2, 3, 2, 2, 2};
+      mbt = 1 + kRaw16[std::min (m.luma16_mode, 6)] + 4 * m.cbp_c + (m.cbp_l ? 12 : 0);
+      s.type_class = 2;
+    } else s.type_class = 1;
+    if (is_p) ce_.encode (14, 1);
+    i_type (!is_p, mbt);
+    if (!i16) {
+      t8 = type == LH264_MB_I8x8;
+      if (H.transform_8x8) t8_flag (t8);
+      s.t8 = t8;
+      const int nblk = t8 ? 4 : 16;
+      for (int i = 0; i < nblk; i++) {
+        const int bx = t8 ? (i & 1) * 2 : z2x (i), by = t8 ? (i >> 1) * 2 : z2y (i);
+        const int pred = pred_intra_mode (k, bx, by, w, sid, H.constrained_intra_pred);
+        const int mode = m.pred_mode[i];
+        ce_.encode (68, mode == pred);
+        if (mode != pred) { const int rem = mode < pred ? mode : mode - 1; ce_.encode (69, rem & 1); ce_.encode (69, (rem >> 1) & 1); ce_.encode (69, (rem >> 2) & 1); }
+        const int n = t8 ? 2 : 1;
+        for (int yy = 0; yy < n; yy++) for (int x = 0; x < n; x++) s.ipm[(by + yy) * 4 + bx + x] = (int8_t)mode;
+      }
+    }
+    static const int kRawChroma[7] = {0, 1, 2, 3, 0, 0, 0};
+    const int cm = kRawChroma[std::min (m.chroma_mode, 6)];
+    {                                                        // intra_chroma_pred_mode, 9.3.3.1.1.8
+      const int cA = kA >= 0 && ws_[kA].type_class != 3 && ws_[kA].chroma_pred != 0;
+      const int cBn = kB >= 0 && ws_[kB].type_class != 3 && ws_[kB].chroma_pred != 0;
+      ce_.encode (64 + cA + cBn, cm != 0);
+      if (cm) { ce_.encode (67, cm != 1); if (cm != 1) ce_.encode (67, cm == 3); }
+    }
+    s.chroma_pred = (uint8_t)cm;
+  } else {
+    s.type_class = 3;
+    const int nref = H.sh.num_ref_idx_l0;
+    ce_.encode (14, 0);
+    if (type == LH264_MB_P16x16) { ce_.encode (15, 0); ce_.encode (16, 0); }
+    else if (type == LH264_MB_P8x8 || type == LH264_MB_P8x8REF0) { ce_.encode (15, 0); ce_.encode (16, 1); }
+    else if (type == LH264_MB_P16x8) { ce_.encode (15, 1); ce_.encode (17, 1); }
+    else { ce_.encode (15, 1); ce_.encode (17, 0); }
+    auto ref_gt0 = [&] (int bx, int by) -> int {
+      int kk = k, x = bx, yy = by;
+      if (x < 0) { kk = kA; x = 3; } else if (yy < 0) { kk = kB; yy = 3; }
+      if (kk < 0) return 0;
+      const WState& t = ws_[kk];
+      if (t.type_class != 3 || t.skip) return 0;
+      return t.ref[(yy >> 1) * 2 + (x >> 1)] > 0;
+    };
+    auto put_ref = [&] (int bx, int by, int v) {
+      if (nref <= 1) return;
+      int inc = ref_gt0 (bx - 1, by) + 2 * ref_gt0 (bx, by - 1);
+      for (int i = 0; i < v; i++) { ce_.encode (54 + inc, 1); inc = i == 0 ? 4 : 5; }
+      ce_.encode (54 + inc, 0);
+    };
+    auto abs_mvd = [&] (int bx, int by, int comp) -> int {
+      int kk = k, x = bx, yy = by;
+      if (x < 0) { kk = kA; x = 3; } else if (yy < 0) { kk = kB; yy = 3; }
+      if (kk < 0) return 0;
+      return ws_[kk].mvd[yy * 4 + x][comp];
+    };
+    auto put_mvd1 = [&] (int bx, int by, int comp, int d) {     // UEG3, uCoff 9, signed (9.3.2.3, 9.3.3.1.1.7)
+      const int base = comp ? 47 : 40;
+      const int sum = abs_mvd (bx - 1, by, comp) + abs_mvd (bx, by - 1, comp);
+      int inc = sum < 3 ? 0 : sum > 32 ? 2 : 1;
+      const int a = std::abs (d);
+      ce_.encode (base + inc, a != 0);
+      if (!a) return;
+      int v = 1;
+      inc = 3;
+      while (v < 9) { const int bin = a > v; ce_.encode (base + inc, bin); if (!bin) break; v++; if (inc < 6) inc++; }
+      if (a >= 9) {
+        int rem = a - 9, kk = 3;
+        while (rem >= (1 << kk)) { ce_.bypass (1); rem -= 1 << kk; kk++; }
+        ce_.bypass (0);
+        while (kk--) ce_.bypass ((rem >> kk) & 1);
+      }
+      ce_.bypass (d < 0);
+    };
+    auto part = [&] (int bx, int by, int bw, int bh) {          // the partition whose motion vector difference sits at (bx,by)
+      const int dx = m.mvd[by * 4 + bx][0], dy = m.mvd[by * 4 + bx][1];
+      put_mvd1 (bx, by, 0, dx); put_mvd1 (bx, by, 1, dy);
+      const uint8_t ax = (uint8_t)std::min (255, std::abs (dx)), ay = (uint8_t)std::min (255, std::abs (dy));
+      for (int yy = by; yy < by + bh; yy++) for (int x = bx; x < bx + bw; x++) { s.mvd[yy * 4 + x][0] = ax; s.mvd[yy * 4 + x][1] = ay; }
+    };
+    if (type == LH264_MB_P16x16 || type == LH264_MB_P16x8 || type == LH264_MB_P8x16) {
+      const int mbt = type == LH264_MB_P16x16 ? 0 : type == LH264_MB_P16x8 ? 1 : 2;
+      const int np = mbt == 0 ? 1 : 2;
+      for (int i = 0; i < np; i++) {
+        const int bx = mbt == 2 ? i * 2 : 0, by = mbt == 1 ? i * 2 : 0;
+        put_ref (bx, by, m.ref_idx[i]);
+        for (int q = 0; q < 4; q++) {
+          const bool in = mbt == 0 || (mbt == 1 ? (q >> 1) == i : (q & 1) == i);
+          if (in) s.ref[q] = (int8_t)m.ref_idx[i];
+        }
+      }
+      for (int i = 0; i < np; i++) {
+        int bx = 0, by = 0, bw = 4, bh = 4;
+        if (mbt == 1) { bh = 2; by = i * 2; } else if (mbt == 2) { bw = 2; bx = i * 2; }
+        part (bx, by, bw, bh);
+      }
+    } else {
+      int sub[4];
+      for (int q = 0; q < 4; q++) {                           // sub_mb_type, Table 9-37
+        sub[q] = m.sub_type[q] == LH264_SUB_8x8 ? 0 : m.sub_type[q] == LH264_SUB_8x4 ? 1 : m.sub_type[q] == LH264_SUB_4x8 ? 2 : 3;
+        if (sub[q] == 0) ce_.encode (21, 1);
+        else { ce_.encode (21, 0); if (sub[q] == 1) ce_.encode (22, 0); else { ce_.encode (22, 1); ce_.encode (23, sub[q] == 2); } }
+      }
+      for (int q = 0; q < 4; q++) { put_ref ((q & 1) * 2, (q >> 1) * 2, m.ref_idx[q]); s.ref[q] = (int8_t)m.ref_idx[q]; }
+      for (int q = 0; q < 4; q++) {
+        const int qx = (q & 1) * 2, qy = (q >> 1) * 2;
+        const int nsp = sub[q] == 0 ? 1 : sub[q] == 3 ? 4 : 2;
+        for (int j = 0; j < nsp; j++) {
+          int bx = qx, by = qy, bw = 2, bh = 2;
+          if (sub[q] == 1) { bh = 1; by += j; } else if (sub[q] == 2) { bw = 1; bx += j; } else if (sub[q] == 3) { bw = bh = 1; bx += j & 1; by += j >> 1; }
+          part (bx, by, bw, bh);
+        }
+      }
+    }
+  }
+  if (!i16) {                                                // coded_block_pattern, 9.3.2.6 / 9.3.3.1.1.4
+    auto luma_bit = [&] (int kk, int b8) -> int {
+      if (kk < 0) return 0;
+      if (ws_[kk].skip) return 1;
+      return ((ws_[kk].cbp >> b8) & 1) ? 0 : 1;
+    };
+    int cl = 0;
+    for (int b8 = 0; b8 < 4; b8++) {
+      const int cA = (b8 & 1) ? (((cl >> (b8 - 1)) & 1) ? 0 : 1) : luma_bit (kA, b8 + 1);
+      const int cBn = (b8 & 2) ? (((cl >> (b8 - 2)) & 1) ? 0 : 1) : luma_bit (kB, b8 + 2);
+      const int bit = (m.cbp_l >> b8) & 1;
+      ce_.encode (73 + cA + 2 * cBn, bit);
+      cl |= bit << b8;
+    }
+    auto chroma_nz = [&] (int kk, int lvl) -> int {
+      if (kk < 0) return 0;
+      if (ws_[kk].skip) return 0;
+      return (ws_[kk].cbp >> 4) >= lvl;
+    };
+    ce_.encode (77 + chroma_nz (kA, 1) + 2 * chroma_nz (kB, 1), m.cbp_c != 0);
+    if (m.cbp_c) ce_.encode (77 + 4 + chroma_nz (kA, 2) + 2 * chroma_nz (kB, 2), m.cbp_c == 2);
+    if (!intra) {
+      bool no_sub_lt8 = true;
+      if (type == LH264_MB_P8x8 || type == LH264_MB_P8x8REF0) for (int q = 0; q < 4; q++) if (m.sub_type[q] != LH264_SUB_8x8) no_sub_lt8 = false;
+      if (m.cbp_l && H.transform_8x8 && no_sub_lt8) { t8 = m.t8 != 0; t8_flag (t8); }
+    }
+  }
+  s.cbp = (uint8_t)cbp;
+  if (t8) s.t8 = 1;
+  if (!(cbp || i16)) { last_dqp = 0; return; }
+  {                                                          // mb_qp_delta, 9.3.2.7 / 9.3.3.1.1.5
+    const int d = (((m.luma_qp - qp_prev) + 26 + 104) % 52) - 26;
+    const int v = d > 0 ? 2 * d - 1 : -2 * d;
+    ce_.encode (60 + (last_dqp != 0 ? 1 : 0), v != 0);
+    if (v) {
+      ce_.encode (62, v >= 2);
+      if (v >= 2) { for (int j = 2; j < v; j++) ce_.encode (63, 1); ce_.encode (63, 0); }
+    }
+    last_dqp = d;
+    qp_prev = m.luma_qp;
+  }
+  int lv[64];
+  if (i16) {
+    for (int i = 0; i < 16; i++) { const int r = kZigzag4x4[i]; lv[i] = m.lev[(((r & 3) & 1) | (((r >> 2) & 1) << 1) | (((r & 3) >> 1) << 2) | (((r >> 2) >> 1) << 3)) * 16]; }
+    cabac_residual (k, 0, 0, 0, true, lv, 16);
+  }
+  for (int i8 = 0; i8 < 4; i8++) {
+    if (!((m.cbp_l >> i8) & 1)) continue;
+    if (t8) {
+      for (int i = 0; i < 64; i++) lv[i] = m.lev[i8 * 64 + kZigzag8x8[i]];
+      cabac_residual (k, 5, i8, 0, intra, lv, 64);
+      for (int j = 0; j < 4; j++) { const int z = i8 * 4 + j; s.cbf |= 1u << (z2y (z) * 4 + z2x (z)); }
+      continue;
+    }
+    for (int j = 0; j < 4; j++) {
+      const int z = i8 * 4 + j, bx = z2x (z), by = z2y (z);
+      const int maxc = i16 ? 15 : 16;
+      for (int i = 0; i < maxc; i++) lv[i] = m.lev[z * 16 + kZigzag4x4[i16 ? i + 1 : i]];
+      cabac_residual (k, i16 ? 1 : 2, by * 4 + bx, 0, intra, lv, maxc);
+    }
+  }
+  if (m.cbp_c) {
+    for (int p = 0; p < 2; p++) {
+      for (int i = 0; i < 4; i++) lv[i] = m.lev[256 + p * 64 + i * 16];
+      cabac_residual (k, 3, 0, p, intra, lv, 4);
+    }
+    if (m.cbp_c == 2) {
+      for (int p = 0; p < 2; p++) for (int j = 0; j < 4; j++) {
+          for (int i = 0; i < 15; i++) lv[i] = m.lev[256 + p * 64 + j * 16 + kZigzag4x4[i + 1]];
+          cabac_residual (k, 4, j, p, intra, lv, 15);
+        }
+    }
+  }
+}
+
 // one slice: the macroblocks in scan order (WelsDecodeSliceForRecoding DS:2476-2830), each written out as CAVLC at once
 bool Restorer::decode_slice (const Parser::HeaderInfo& H) {
   const int w = H.mb_w, n = H.mb_w * H.mb_h;
@@ -529,9 +893,13 @@ bool Restorer::decode_slice (const Parser::HeaderInfo& H) {
   }
   std::vector<Cell>& cur = img_[cur_];
   std::vector<Cell>& last = img_[1 - cur_];
-  const bool is_p = H.sh.slice_type == 0;
+  const bool is_p = H.sh.slice_type == 0, cabac = H.cabac;
   const int st = H.sh.slice_type;
-  int skip_state = -1, mb_in_slice = 0, cached_qp = 0, last_nonzero_dqp = 0, qp_prev = H.sh.slice_qp;
+  int skip_state = -1, mb_in_slice = 0, cached_qp = 0, last_nonzero_dqp = 0, qp_prev = H.sh.slice_qp, last_dqp = 0;
+  if (cabac) {                                       // cabac_alignment_one_bit, then the arithmetic codeword (7.3.4, 9.3.1)
+    while (w_.bits_in_byte()) w_.emit_bit (1);
+    ce_.init (is_p ? 1 + H.sh.cabac_init_idc : 0, H.sh.slice_qp);
+  }
   uint32_t pending_skips = 0;
   MbDec m;
   for (int k = H.sh.first_mb; ; k++, mb_in_slice++) {
@@ -543,12 +911,13 @@ bool Restorer::decode_slice (const Parser::HeaderInfo& H) {
     const Cell* np = (prior_valid && last[k].initialized) ? &last[k] : nullptr;
     int mb_skip_run = 0;
     const uint32_t stop_idx = (uint32_t) (mb_in_slice < 2048 ? mb_in_slice : 2047);
-    if (skip_state == -1) {
+    if (skip_state == -1 || cabac) {                 // CABAC: a run of 0 or 1 for every macroblock (DS:2505-2516)
       const int pr = np ? np->cached_skips / 8 + (np->cached_skips % 8 ? 1 : 0) : 0;
       const int run = (int)tree (TAG_SKIP, LH264_TB_SKIPRUN, (uint32_t) (pr * 16 + 11));
-      if (is_p) skip_state = run; else mb_skip_run = run;
+      if (is_p && !cabac) skip_state = run; else mb_skip_run = run;
+      if (cabac && run > 1) { fail ("corrupt skip flag"); return false; }
     }
-    if (is_p) { mb_skip_run = skip_state; skip_state--; }
+    if (is_p && !cabac) { mb_skip_run = skip_state; skip_state--; }
     bool has_stop = false;
     if (mb_skip_run == 1) has_stop = scan_bit (TAG_SKIP_END, store_.get (LH264_TB_STOP, stop_idx)) != 0;
     if (mb_skip_run != 0) {
@@ -557,7 +926,8 @@ bool Restorer::decode_slice (const Parser::HeaderInfo& H) {
       nxn_[k] = 0;
       WState& s = ws_[k];
       s.slice = sid_; s.mb_type = LH264_MB_SKIP; s.type_class = 3; memset (s.nzc, 0, 24); for (int i = 0; i < 16; i++) s.ipm[i] = 2;
-      pending_skips++;
+      if (cabac) { write_mb_cabac (H, k, nullptr, qp_prev, last_dqp); ce_.terminate (has_stop); }
+      else pending_skips++;
       if (has_stop) break;
       continue;
     }
@@ -693,9 +1063,21 @@ bool Restorer::decode_slice (const Parser::HeaderInfo& H) {
     for (int i = 0; i < 384; i++) if (m.lev[i]) { e.zeroed = 0; break; }
     cur[k] = e;
     // the bits
-    if (is_p) { put_ue (pending_skips); pending_skips = 0; }
-    write_mb (H, k, m, qp_prev);
+    if (cabac) { write_mb_cabac (H, k, &m, qp_prev, last_dqp); ce_.terminate (has_stop); }
+    else {
+      if (is_p) { put_ue (pending_skips); pending_skips = 0; }
+      write_mb (H, k, m, qp_prev);
+    }
     if (has_stop) break;
+  }
+  if (cabac) {
+    // the arithmetic codeword ends with the rbsp stop bit; the reference then overwrites the low 7 bits of its last byte with
+    // what the compressor saw there (copySBitStringAux DS:1297-1333 with the 7 pad bits of DS:3133-3148)
+    const unsigned pad_value = scan_raw_bits (TAG_PADBYTE, 7);
+    if (ce_.bytes.empty()) { fail ("empty CABAC slice"); return false; }
+    ce_.bytes.back() = (uint8_t) ((ce_.bytes.back() & 0x80) | pad_value);
+    w_.append_bytes (ce_.bytes.data(), ce_.bytes.size());
+    return !failed_;
   }
   if (pending_skips) put_ue (pending_skips);
   // rbsp_slice_trailing_bits: the stop bit, then the alignment bits as the compressor saw them (DS:3133-3148)
@@ -739,8 +1121,17 @@ int Restorer::run (const uint8_t* d, size_t n, std::vector<uint8_t>& out) {
       while (!esc.empty() && esc.back() == 0) esc.pop_back();
       if (type == 1 || type == 5) {
         Parser::HeaderInfo H;
-        if (hdr_.parse_headers (esc.data(), esc.size(), H) < 0 || !H.is_slice) { fail ("slice header: " + hdr_.error()); break; }
-        if (H.cabac) { fail ("CABAC slices are not supported by the restore direction yet"); break; }
+        // (a CABAC slice leaves only its header in the default stream, zero-padded to the byte: trailing zero bytes are header bits)
+        std::vector<uint8_t> hb (c + off, c + len);
+        hb.insert (hb.end(), 4, 0);
+        if (hdr_.parse_headers (hb.data(), hb.size(), H) < 0 || !H.is_slice) { fail ("cannot parse a slice header of the default stream (" + hdr_.error() + ")"); break; }
+        if (H.cabac) {
+          // The header of a CABAC slice is all its NAL keeps in the default stream, zero-padded to the byte.  When it ends in zero
+          // bytes, cutting the stream at start codes hands those to the following chunk as if they were zeros before a start
+          // code (the reference then writes them in the wrong place and cannot restore such streams): take them back.
+          size_t need = 1 + ((size_t)H.hdr_bits + 7) / 8;
+          for (size_t have = nal.size(); have < need && pos < n && d[pos] == 0; have++) pos++;
+        }
         const std::vector<uint8_t>& rb = hdr_.last_rbsp();
         for (int b = 0; b < H.hdr_bits; b++) w_.emit_bit ((rb[(size_t)b >> 3] >> (7 - (b & 7))) & 1);
         if (!decode_slice (H)) break;

@@ -10,7 +10,8 @@
 //   * a CAVLC macroblock-layer writer straight from ITU-T H.264 7.3.5 / 9.2 (the reference borrows its encoder's writer,
 //     encoder/core/src/svc_set_mb_syn_cavlc.cpp:266-320 via decoder/core/inc/encoder_from_decoder.h)
 // The adaptive decode is serial by nature (every prior depends on the values decoded before it); this first version runs it
-// on the host, one stream per thread.  CABAC slices and I_PCM macroblocks are reported as unsupported.
+// on the host, one stream per thread.  CABAC slices go through a CABAC macroblock writer (9.3.2-9.3.4, the mirror image of the
+// front end's CABAC parser).  I_PCM macroblocks are reported as unsupported.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>

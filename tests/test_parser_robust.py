@@ -33,7 +33,7 @@ def test_restore_survives_damaged_files(tmp_path):
                            os.path.join(host, "h264_parser.cpp"), os.path.join(host, "pip_symbols.cpp"),
                            os.path.join(host, "pip_restore.cpp"), "-o", exe])
     bases = []
-    for name in ("SVA_BA2_D.264", "SVA_BA1_B.264", "test_vd_1d.264", "CI_MW_D.264", "tibby8x8cavlc.264"):
+    for name in ("SVA_BA2_D.264", "SVA_BA1_B.264", "test_vd_1d.264", "CI_MW_D.264", "tibby8x8cavlc.264", "test_qcif_cabac.264", "tibbycabac.264"):
         z = np.load(os.path.join(ROOT, "tests", "golden", "cli_" + name + ".npz"))
         base = str(tmp_path / name.rsplit(".", 1)[0])
         with open(base + ".264", "wb") as f:
