@@ -91,6 +91,13 @@ __device__ __forceinline__ void bc_finish (Bc& b, GLB uint8_t* out, uint32_t cap
   if ((b.last & 0xe0) == 0xc0) bc_put (b, out, cap, 0);
 }
 
+#ifdef LH264_CODER_STAMP
+#define STAMP_FIELDS uint64_t st_t, st_acc[8];
+#define STAMP(c, i) { const uint64_t st_n = __builtin_amdgcn_s_memtime(); (c).st_acc[i] += st_n - (c).st_t; (c).st_t = st_n; }
+#else
+#define STAMP_FIELDS
+#define STAMP(c, i)
+#endif
 // ---- the wave's coding context ---------------------------------------------------------------------------------------------
 struct Coder {
   GLB uint32_t* keys; GLB uint32_t* cells; uint32_t mask;
@@ -101,6 +108,7 @@ struct Coder {
   uint32_t test_prob;      // TEST_PROB, wave-uniform
   int status;
   Bc bc;                   // this lane's tag
+  STAMP_FIELDS
 };
 
 __device__ __forceinline__ int tag_slot (int tag) { return tag == 69 ? 34 : tag; }
@@ -145,14 +153,14 @@ __device__ __forceinline__ void touch_tag (Coder& c, int tag) {       // a strea
 // A word with bit 31 set switches cells: the next word is the key (+1) of the cell the following decisions use (priors
 // that are trees of more than 16 nodes span several cells).
 #define DL_STRIDE 56
-struct DList { uint32_t* row; int n; };            // row: LDS
+struct DList { uint32_t* row; int n; unsigned long long raw; bool sw; };            // row: LDS; raw: which entries are raw bits; sw: a cell switch occurs
 __device__ __forceinline__ void push (DList& d, int j, int bit, int tag) {
-  if (d.n < DL_STRIDE) d.row[d.n] = (uint32_t) (j & 0xff) | ((uint32_t) (bit & 1) << 8) | ((uint32_t)tag << 16);
+  if (d.n < DL_STRIDE) { d.row[d.n] = (uint32_t) (j & 0xff) | ((uint32_t) (bit & 1) << 8) | ((uint32_t)tag << 16); if ((j & 0xff) == 0xff) d.raw |= 1ull << d.n; }
   d.n++;
 }
 __device__ __forceinline__ void push_switch (DList& d, uint32_t key) {
   if (d.n + 1 < DL_STRIDE) { d.row[d.n] = 0x80000000u; d.row[d.n + 1] = key + 1u; }
-  d.n += 2;
+  d.n += 2; d.sw = true;
 }
 // UnaryIntPrior<n>::at(i) = prior[min(i, n-1)]; emitUnary compression_stream.h:465-474
 __device__ __forceinline__ void b_unary (DList& d, int data, int base, int n, int early, int tag) {
@@ -258,6 +266,9 @@ __device__ __forceinline__ uint32_t build_symbol (DList& d, uint32_t prior, int 
 __device__ __forceinline__ void decide (Coder& c, uint32_t w) {
   const int j = (int) (w & 0xffu), bit = (int) ((w >> 8) & 1u), tag = (int) ((w >> 16) & 0xffu);
   int prob;
+#ifdef LH264_CODER_ABL_NODP
+  prob = 128 + (j & 1);
+#else
   if (j == 0xff) { prob = dp_prob (c.test_prob); c.test_prob = dp_update (c.test_prob, bit); }
   else {
     const uint32_t s = (uint32_t)__builtin_amdgcn_readlane ((int)c.cellv, j);
@@ -265,6 +276,7 @@ __device__ __forceinline__ void decide (Coder& c, uint32_t w) {
     const uint32_t ns = dp_update (s, bit);
     if (c.lane == j) c.cellv = ns;
   }
+#endif
   const int slot = tag_slot (tag);
 #ifndef LH264_CODER_ABL_NOBC
   if (c.lane == slot) bc_write (c.bc, c.out + (size_t)slot * c.cap, c.cap, bit, prob);
@@ -278,21 +290,25 @@ __device__ __forceinline__ void decide (Coder& c, uint32_t w) {
 // fetches it into the wave's LDS rows, all in parallel; the decisions are then executed strictly in order, a cell shared by
 // several symbols of the batch living in the row of the first of them; cells not found (new priors) and priors spanning
 // several cells go to the table serially.
-__device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, uint32_t* bcell /* LDS [64][16] */, uint32_t* dl /* LDS [64][DL_STRIDE] */) {
+__device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, uint32_t* bcell /* LDS [64][16] */, uint32_t* dl /* LDS [64][DL_STRIDE] */,
+                                            uint32_t* sorted /* LDS [64 * DL_STRIDE] */) {
   const int lane = c.lane;
   const uint32_t prior = (uint32_t)sym, hi = (uint32_t) (sym >> 32);
-  DList d; d.row = dl + lane * DL_STRIDE; d.n = 0;
+  DList d; d.row = dl + lane * DL_STRIDE; d.n = 0; d.raw = 0ull; d.sw = false;
   int touch = -1;
   uint32_t key = 0;
   if (lane < count) key = build_symbol (d, prior, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24), touch);
   if (d.n > DL_STRIDE) c.status = 8;
   const int nd = d.n;
+  STAMP (c, 1)
   // the row of a cell = the first lane of the batch that uses it
-  int owner = lane;
+  int owner = lane, rank = 0;                        // rank: how many earlier symbols of the batch use the same cell
   for (int j = 0; j < count; j++) {
     const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane ((int)key, j);
     if (kj == key && j < owner) owner = j;
+    if (kj == key && j < lane) rank++;
   }
+  STAMP (c, 2)
   // parallel probe + fetch by the owners
   uint32_t slot = 0; bool found = false;
   if (key != 0u && owner == lane) {
@@ -316,6 +332,125 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
   }
   unsigned long long valid = __ballot (found);
   __builtin_amdgcn_wave_barrier();
+  STAMP (c, 3)
+#ifndef LH264_CODER_SERIAL
+  // ---- the parallel way: no cell switch in the batch, every cell found --------------------------------------------------
+  // The adaptive state of a DynProb depends only on the decisions made with that DynProb, the bool coder of a tag only on the
+  // (probability, bit) pairs sent to that tag: so (1) TEST_PROB walks the raw bits of the batch in order, (2) every cell row is
+  // advanced by the lanes whose symbols use it, one user after the other, all rows at once, each decision word taking the
+  // probability it is coded with, (3) the words are sorted by tag, order kept, (4) lane t codes the list of tag slot t.
+  const bool is_user = lane < count && key != 0u;
+  if (!__ballot (d.sw || nd > DL_STRIDE || (is_user && !((valid >> owner) & 1ull)))) {
+    uint32_t* row = dl + lane * DL_STRIDE;
+    {                                                  // a stream exists once one of its symbols was billed (EXP tags)
+      unsigned long long tl = __ballot (touch >= 0);
+      while (tl) {
+        const int i = __ffsll ((long long)tl) - 1;
+        const int ti = __builtin_amdgcn_readlane (touch, i);
+        touch_tag (c, ti);
+        tl &= ~__ballot (touch == ti);
+      }
+    }
+    {                                                  // (1)
+      unsigned long long rl = __ballot (d.raw != 0ull);
+      while (rl) {
+        const int i = __ffsll ((long long)rl) - 1;
+        rl &= rl - 1ull;
+        unsigned long long m = ((unsigned long long) (uint32_t)__builtin_amdgcn_readlane ((int) (d.raw >> 32), i) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane ((int) (d.raw & 0xffffffffu), i);
+        while (m) {
+          const int t = __ffsll ((long long)m) - 1;
+          m &= m - 1ull;
+          const uint32_t w = dl[i * DL_STRIDE + t];
+          const int prob = dp_prob (c.test_prob);
+          c.test_prob = dp_update (c.test_prob, (int) ((w >> 8) & 1u));
+          if (lane == 0) dl[i * DL_STRIDE + t] = (w & 0x00ffffffu) | ((uint32_t)prob << 24);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (2) and the tags a symbol uses (at most four), with their counts
+    int s0 = -1, s1 = -1, s2 = -1, s3 = -1, n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    bool many = false;
+    {
+      int maxrank = 0;
+      for (unsigned long long b = __ballot (is_user && rank > 0); b; ) { maxrank++; b = __ballot (is_user && rank > maxrank); }
+      uint32_t* cr = bcell + owner * 16;
+      for (int rnd = 0; rnd <= maxrank; rnd++) {
+        if ((is_user && rank == rnd) || (rnd == 0 && !is_user)) {
+          for (int t = 0; t < nd; t++) {
+            uint32_t w = row[t];
+            const int j = (int) (w & 0xffu);
+            if (j != 0xff) {
+              const uint32_t sv = cr[j];
+              w = (w & 0x00ffffffu) | ((uint32_t)dp_prob (sv) << 24);
+              cr[j] = dp_update (sv, (int) ((w >> 8) & 1u));
+              row[t] = w;
+            }
+            const int sl = tag_slot ((int) ((w >> 16) & 0xffu));
+            if (sl == s0) n0++; else if (sl == s1) n1++; else if (sl == s2) n2++; else if (sl == s3) n3++;
+            else if (s0 < 0) { s0 = sl; n0 = 1; } else if (s1 < 0) { s1 = sl; n1 = 1; } else if (s2 < 0) { s2 = sl; n2 = 1; }
+            else if (s3 < 0) { s3 = sl; n3 = 1; } else many = true;
+          }
+        }
+        asm volatile ("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (__ballot (many)) c.status = 16;                // cannot happen with the binarisations above
+    // (3) per tag: where each symbol's decisions go
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0, my_seg = 0, my_tot = 0, running = 0;
+    {
+      unsigned long long used = 0ull;
+      for (int T = 0; T < LH264_N_TAG_SLOTS; T++) if (__ballot (s0 == T || s1 == T || s2 == T || s3 == T)) used |= 1ull << T;
+      while (used) {
+        const int T = __ffsll ((long long)used) - 1;
+        used &= used - 1ull;
+        const int v = (s0 == T ? n0 : 0) + (s1 == T ? n1 : 0) + (s2 == T ? n2 : 0) + (s3 == T ? n3 : 0);
+        int incl = v;
+        for (int dd = 1; dd < 64; dd <<= 1) { const int u = __shfl_up (incl, dd); if (lane >= dd) incl += u; }
+        const int tot = __builtin_amdgcn_readlane (incl, 63);
+        const int at = running + incl - v;
+        if (s0 == T) b0 = at; else if (s1 == T) b1 = at; else if (s2 == T) b2 = at; else if (s3 == T) b3 = at;
+        if (lane == T) { my_seg = running; my_tot = tot; }
+        running += tot;
+      }
+    }
+    for (int t = 0; t < nd; t++) {
+      const uint32_t w = row[t];
+      const int sl = tag_slot ((int) ((w >> 16) & 0xffu));
+      int at;
+      if (sl == s0) at = b0++; else if (sl == s1) at = b1++; else if (sl == s2) at = b2++; else at = b3++;
+      sorted[at] = w;
+    }
+    asm volatile ("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // (4)
+    {
+      GLB uint8_t* o = c.out + (size_t)lane * c.cap;
+      for (int q = 0; __ballot (q < my_tot); q++) {
+        if (q < my_tot) {
+          const uint32_t w = sorted[my_seg + q];
+#ifndef LH264_CODER_ABL_NOBC
+          bc_write (c.bc, o, c.cap, (int) ((w >> 8) & 1u), (int) (w >> 24));
+#else
+          c.bc.low += w >> 24;
+#endif
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    STAMP (c, 4)
+    if (key != 0u && owner == lane && ((valid >> lane) & 1ull)) {
+      GLB u32x4* dst = (GLB u32x4*) (c.cells + (size_t)slot * 16);
+      const u32x4* src = (const u32x4*) (bcell + lane * 16);
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    }
+    __builtin_amdgcn_wave_barrier();
+    STAMP (c, 5)
+    return;
+  }
+#endif
   for (int i = 0; i < count; i++) {
     const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane ((int)key, i);
     const int r = __builtin_amdgcn_readlane (owner, i);
@@ -348,6 +483,7 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
     else cell_flush (c);
   }
   __builtin_amdgcn_wave_barrier();
+  STAMP (c, 4)
   // write the rows back
   if (key != 0u && owner == lane && ((valid >> lane) & 1ull)) {
     GLB u32x4* dst = (GLB u32x4*) (c.cells + (size_t)slot * 16);
@@ -355,6 +491,7 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
   }
   __builtin_amdgcn_wave_barrier();
+  STAMP (c, 5)
 }
 
 __global__ void __launch_bounds__ (64)
@@ -362,6 +499,7 @@ coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __
                     const lh264_code_stream_t* __restrict__ streams, int n_chains) {
   __shared__ uint32_t bcell[64 * 16];
   __shared__ uint32_t dl[64 * DL_STRIDE];
+  __shared__ uint32_t sorted[64 * DL_STRIDE];
   __shared__ uint64_t queue[128];
   const int chain = blockIdx.x;
   if (chain >= n_chains) return;
@@ -372,6 +510,9 @@ coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __
   c.lane = (int)threadIdx.x;
   c.cellv = 0; c.cur_key = 0; c.cur_slot = 0; c.have_cell = false; c.test_prob = 0; c.status = 0;
   c.bc.used = 0; c.bc.pos = 0; c.bc.low = 0; c.bc.range = 255; c.bc.count = -24; c.bc.ffrun = 0; c.bc.pending = -1; c.bc.last = 0;
+#ifdef LH264_CODER_STAMP
+  c.st_t = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 8; i++) c.st_acc[i] = 0;
+#endif
   const int lane = c.lane;
   // One loop, one copy of the coder: fill the queue from the stream's symbol sources (host list of macroblock k, with the
   // coefficient symbols of macroblock k in place of the marker), then code a batch of up to 64.
@@ -417,18 +558,23 @@ coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __
       if (spl) { base++; mc = uniform ((int)cn[k]); cb = 0; in_ctx = mc > 0; }
     }
     if (qn == 0) break;
+    STAMP (c, 0)
     // ---- code ---------------------------------------------------------------------------------------------------------
     __builtin_amdgcn_wave_barrier();
     const int m = qn < 64 ? qn : 64;
     const uint64_t sym = lane < m ? queue[lane] : 0ull;
     const uint64_t mv = queue[64 + lane];
     __builtin_amdgcn_wave_barrier();
-    code_batch (c, sym, m, bcell, dl);
+    code_batch (c, sym, m, bcell, dl, sorted);
     if (qn > 64) queue[lane] = mv;                   // what is left moves to the front
     qn -= m;
     __builtin_amdgcn_wave_barrier();
   }
   cell_flush (c);
+  STAMP (c, 6)
+#ifdef LH264_CODER_STAMP
+  if (c.lane == 0) { GLB uint64_t* dbg = (GLB uint64_t*) (c.out + (size_t)39 * c.cap); for (int i = 0; i < 8; i++) dbg[i] = c.st_acc[i]; }
+#endif
   GLB uint32_t* lens = glb<uint32_t> (S->out_len_dev);
   if (c.lane < LH264_N_TAG_SLOTS) {
     if (c.bc.used) bc_finish (c.bc, c.out + (size_t)c.lane * c.cap, c.cap);

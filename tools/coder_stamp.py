@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""phase breakdown of the device coder (diagnostic build -DLH264_CODER_STAMP): s_memtime per phase, summed per wave"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import losslessh264_amd as lh
+from losslessh264_amd import _lib as L
+data = open(os.path.join(ROOT, "tests", "golden", "streams", "BA_MW_D.264"), "rb").read()
+frames, err = lh.parse_stream(data)
+streams = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+ctx = lh.CtxSession([frames], replicate=streams)
+coder = lh.CoderSession(ctx)
+ctx.run(); coder.run(); ctx.synchronize()
+out = coder.d_out.cpu().numpy().reshape(streams, L.N_TAG_SLOTS, coder.out_cap)
+names = ["fill", "binarise", "owner", "probe+fetch", "execute", "writeback", "tail", "-"]
+acc = out[:, 39, :64].copy().view(np.uint64).astype(np.float64)     # [streams][8]
+tot = acc.sum(axis=1).mean()
+for i, n in enumerate(names):
+    print("%-12s %6.1f %%   %.2f ms at 100 MHz" % (n, 100 * acc[:, i].mean() / tot, acc[:, i].mean() / 1e5))
