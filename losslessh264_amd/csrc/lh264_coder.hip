@@ -24,6 +24,21 @@ typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
 template <typename T> __device__ __forceinline__ GLB T* glb (const void* p) { return (GLB T*) (uintptr_t)p; }
 __device__ __forceinline__ int uniform (int v) { return __builtin_amdgcn_readfirstlane (v); }
 
+// ---- wave-wide inclusive scan / OR over 64 lanes with DPP: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8), then lane 15
+// of rows 0 and 2 into rows 1 and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31).  Lanes without a source add 0.
+template <int CTRL, int ROWS> __device__ __forceinline__ int dpp0 (int x) { return __builtin_amdgcn_update_dpp (0, x, CTRL, ROWS, 0xf, false); }
+__device__ __forceinline__ int wave_scan_add (int x) {
+  x += dpp0<0x111, 0xf> (x); x += dpp0<0x112, 0xf> (x); x += dpp0<0x114, 0xf> (x); x += dpp0<0x118, 0xf> (x);
+  x += dpp0<0x142, 0xa> (x); x += dpp0<0x143, 0xc> (x);
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_or (uint32_t v) {
+  int x = (int)v;
+  x |= dpp0<0x111, 0xf> (x); x |= dpp0<0x112, 0xf> (x); x |= dpp0<0x114, 0xf> (x); x |= dpp0<0x118, 0xf> (x);
+  x |= dpp0<0x142, 0xa> (x); x |= dpp0<0x143, 0xc> (x);
+  return (uint32_t)__builtin_amdgcn_readlane (x, 63);
+}
+
 // ---- DynProb, packed -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int dp_prob (uint32_t s) { return (int) (((s >> 20) + 128u) & 255u); }
 __device__ __forceinline__ uint32_t dp_update (uint32_t s, int bit) {
@@ -92,7 +107,7 @@ __device__ __forceinline__ void bc_finish (Bc& b, GLB uint8_t* out, uint32_t cap
 }
 
 #ifdef LH264_CODER_STAMP
-#define STAMP_FIELDS uint64_t st_t, st_acc[8];
+#define STAMP_FIELDS uint64_t st_t, st_acc[12];
 #define STAMP(c, i) { const uint64_t st_n = __builtin_amdgcn_s_memtime(); (c).st_acc[i] += st_n - (c).st_t; (c).st_t = st_n; }
 #else
 #define STAMP_FIELDS
@@ -369,6 +384,7 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
       }
     }
     __builtin_amdgcn_wave_barrier();
+    STAMP (c, 7)
     // (2) and the tags a symbol uses (at most four), with their counts
     int s0 = -1, s1 = -1, s2 = -1, s3 = -1, n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     bool many = false;
@@ -397,18 +413,18 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
         __builtin_amdgcn_wave_barrier();
       }
     }
+    STAMP (c, 8)
     if (__ballot (many)) c.status = 16;                // cannot happen with the binarisations above
     // (3) per tag: where each symbol's decisions go
     int b0 = 0, b1 = 0, b2 = 0, b3 = 0, my_seg = 0, my_tot = 0, running = 0;
     {
-      unsigned long long used = 0ull;
-      for (int T = 0; T < LH264_N_TAG_SLOTS; T++) if (__ballot (s0 == T || s1 == T || s2 == T || s3 == T)) used |= 1ull << T;
+      const unsigned long long mine = (s0 >= 0 ? 1ull << s0 : 0ull) | (s1 >= 0 ? 1ull << s1 : 0ull) | (s2 >= 0 ? 1ull << s2 : 0ull) | (s3 >= 0 ? 1ull << s3 : 0ull);
+      unsigned long long used = (unsigned long long)wave_or ((uint32_t)mine) | ((unsigned long long)wave_or ((uint32_t) (mine >> 32)) << 32);
       while (used) {
         const int T = __ffsll ((long long)used) - 1;
         used &= used - 1ull;
         const int v = (s0 == T ? n0 : 0) + (s1 == T ? n1 : 0) + (s2 == T ? n2 : 0) + (s3 == T ? n3 : 0);
-        int incl = v;
-        for (int dd = 1; dd < 64; dd <<= 1) { const int u = __shfl_up (incl, dd); if (lane >= dd) incl += u; }
+        const int incl = wave_scan_add (v);
         const int tot = __builtin_amdgcn_readlane (incl, 63);
         const int at = running + incl - v;
         if (s0 == T) b0 = at; else if (s1 == T) b1 = at; else if (s2 == T) b2 = at; else if (s3 == T) b3 = at;
@@ -416,6 +432,7 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
         running += tot;
       }
     }
+    STAMP (c, 9)
     for (int t = 0; t < nd; t++) {
       const uint32_t w = row[t];
       const int sl = tag_slot ((int) ((w >> 16) & 0xffu));
@@ -425,6 +442,7 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
     }
     asm volatile ("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    STAMP (c, 10)
     // (4)
     {
       GLB uint8_t* o = c.out + (size_t)lane * c.cap;
@@ -440,7 +458,7 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
       }
     }
     __builtin_amdgcn_wave_barrier();
-    STAMP (c, 4)
+    STAMP (c, 11)
     if (key != 0u && owner == lane && ((valid >> lane) & 1ull)) {
       GLB u32x4* dst = (GLB u32x4*) (c.cells + (size_t)slot * 16);
       const u32x4* src = (const u32x4*) (bcell + lane * 16);
@@ -511,7 +529,7 @@ coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __
   c.cellv = 0; c.cur_key = 0; c.cur_slot = 0; c.have_cell = false; c.test_prob = 0; c.status = 0;
   c.bc.used = 0; c.bc.pos = 0; c.bc.low = 0; c.bc.range = 255; c.bc.count = -24; c.bc.ffrun = 0; c.bc.pending = -1; c.bc.last = 0;
 #ifdef LH264_CODER_STAMP
-  c.st_t = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 8; i++) c.st_acc[i] = 0;
+  c.st_t = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 12; i++) c.st_acc[i] = 0;
 #endif
   const int lane = c.lane;
   // One loop, one copy of the coder: fill the queue from the stream's symbol sources (host list of macroblock k, with the
@@ -573,7 +591,7 @@ coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __
   cell_flush (c);
   STAMP (c, 6)
 #ifdef LH264_CODER_STAMP
-  if (c.lane == 0) { GLB uint64_t* dbg = (GLB uint64_t*) (c.out + (size_t)39 * c.cap); for (int i = 0; i < 8; i++) dbg[i] = c.st_acc[i]; }
+  if (c.lane == 0) { GLB uint64_t* dbg = (GLB uint64_t*) (c.out + (size_t)39 * c.cap); for (int i = 0; i < 12; i++) dbg[i] = c.st_acc[i]; }
 #endif
   GLB uint32_t* lens = glb<uint32_t> (S->out_len_dev);
   if (c.lane < LH264_N_TAG_SLOTS) {

@@ -13,8 +13,8 @@ ctx = lh.CtxSession([frames], replicate=streams)
 coder = lh.CoderSession(ctx)
 ctx.run(); coder.run(); ctx.synchronize()
 out = coder.d_out.cpu().numpy().reshape(streams, L.N_TAG_SLOTS, coder.out_cap)
-names = ["fill", "binarise", "owner", "probe+fetch", "execute", "writeback", "tail", "-"]
-acc = out[:, 39, :64].copy().view(np.uint64).astype(np.float64)     # [streams][8]
+names = ["fill", "binarise", "owner+rank", "probe+fetch", "serial execute", "writeback", "tail", "touch+raw bits", "cell rows", "tag scans", "scatter", "bool coders"]
+acc = out[:, 39, :96].copy().view(np.uint64).astype(np.float64)     # [streams][12]
 tot = acc.sum(axis=1).mean()
 for i, n in enumerate(names):
-    print("%-12s %6.1f %%   %.2f ms at 100 MHz" % (n, 100 * acc[:, i].mean() / tot, acc[:, i].mean() / 1e5))
+    print("%-16s %6.1f %%" % (n, 100 * acc[:, i].mean() / tot))
