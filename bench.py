@@ -183,12 +183,15 @@ def main():
             # restore direction (adaptive decode + CAVLC writer), one stream per thread, bounded to a few seconds each
             ncpu = min(16, len(os.sched_getaffinity(0)))      # a one-GPU box's CPU share is 16 cores
             nb = 8 * ncpu
-            pt, _ = lh.parse_batch_time([data] * nb, ncpu)
+            pt, npic = lh.parse_batch_time([data] * nb, ncpu, keep=False)     # pictures released as a pipeline would
+            assert npic == nb * len(frames)
+            pk, _ = lh.parse_batch_time([data] * nb, ncpu, keep=True)        # every picture of every stream held in memory
             t0 = time.perf_counter()
             outs = lh.restore_batch([(main_stream, tags)] * nb, ncpu)
             rt = time.perf_counter() - t0
             assert all(o == data for o in outs)
             roundtrip["host_stages"] = {"threads": ncpu, "streams": nb, "front_end_MB_per_s": nb * stream_bytes / pt / 1e6,
+                                        "front_end_keep_all_MB_per_s": nb * stream_bytes / pk / 1e6,
                                         "restore_MB_per_s": nb * stream_bytes / rt / 1e6}
         coder_info["roundtrip"] = roundtrip
         del coder

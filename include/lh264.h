@@ -323,6 +323,9 @@ const char* lh264_restore_error (void);       /* message of the calling thread's
  * hardware thread).  parsers_out[i] is always a valid handle to destroy; its error text tells whether the stream parsed.
  * lh264_pip_restore_batch: n restores as lh264_pip_restore, item by item; item.status receives the return code. */
 int lh264_parse_batch (const uint8_t* const* data, const size_t* len, int n, int threads, lh264_parser_t** parsers_out);
+/* the same work with every picture released as soon as it is complete (what a pipeline does once the records are on their way
+ * to the device): pictures_out[i] = pictures parsed of stream i.  The steady-state throughput probe of the front end. */
+int lh264_parse_batch_discard (const uint8_t* const* data, const size_t* len, int n, int threads, int64_t* pictures_out);
 typedef struct lh264_restore_item {
   const uint8_t* main_stream; size_t main_len;
   const uint8_t* const* tags; const size_t* tag_len; int32_t n_tags;

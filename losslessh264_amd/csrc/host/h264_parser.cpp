@@ -422,7 +422,8 @@ struct Parser::Impl {
       else { cur->syn_off.assign ((size_t)cur->mb_w * cur->mb_h + 1, 0); cur->syn_syms.clear(); }
     }
     cur->complete = true;
-    self->frames_.push_back (std::move (cur));
+    self->pictures_done_++;
+    if (self->keep_frames_) self->frames_.push_back (std::move (cur));
     cur.reset();
     last_first_mb = -1;
   }

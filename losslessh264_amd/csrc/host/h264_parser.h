@@ -199,6 +199,10 @@ class Parser {
   const std::string& error() const { return err_; }       // first error since construction / clear_error()
   void clear_error() { err_.clear(); }
   int unsupported_count() const { return n_unsupported_; }
+  // keep == false: a completed picture is counted and released at once (its buffers go back to the per-thread cache), as a
+  // pipeline does after handing the records to the device; frames() then stays empty
+  void set_keep_frames (bool keep) { keep_frames_ = keep; }
+  long pictures_done() const { return pictures_done_; }
 
  private:
   struct Impl;
@@ -206,6 +210,7 @@ class Parser {
   std::vector<std::unique_ptr<FrameOut>> frames_;
   std::string err_;
   int n_unsupported_ = 0;
+  bool keep_frames_ = true; long pictures_done_ = 0;
   MainStreamWriter main_;
   friend struct Impl;
 };

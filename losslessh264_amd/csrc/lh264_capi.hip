@@ -230,6 +230,16 @@ int lh264_parse_batch (const uint8_t* const* data, const size_t* len, int n, int
   run_parallel (n, threads, [&] (int i) { if (data[i] || !len[i]) parsers_out[i]->p.feed_file (data[i], len[i]); });
   return LH264_OK;
 }
+int lh264_parse_batch_discard (const uint8_t* const* data, const size_t* len, int n, int threads, int64_t* pictures_out) {
+  if (!data || !len || !pictures_out || n < 0) return LH264_E_ARG;
+  run_parallel (n, threads, [&] (int i) {
+    lh264host::Parser p;
+    p.set_keep_frames (false);
+    if (data[i] || !len[i]) p.feed_file (data[i], len[i]);
+    pictures_out[i] = p.pictures_done();
+  });
+  return LH264_OK;
+}
 int lh264_pip_restore_batch (lh264_restore_item_t* items, int n, int threads) {
   if (!items || n < 0) return LH264_E_ARG;
   run_parallel (n, threads, [&] (int i) {

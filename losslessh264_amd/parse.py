@@ -16,14 +16,20 @@ def parse_file(data, strict=False):
     return parse_stream(data, strict, _file=True)
 
 
-def parse_batch_time(datas, threads=0):
-    """parse a batch of Annex-B files on host threads (C ABI lh264_parse_batch) and throw the records away:
-    -> (seconds, pictures parsed).  For the host-throughput line of bench.py."""
+def parse_batch_time(datas, threads=0, keep=True):
+    """parse a batch of Annex-B files on host threads and throw the records away -> (seconds, pictures parsed).
+    keep=True: C ABI lh264_parse_batch (all pictures of all streams stay in memory until the end); keep=False:
+    lh264_parse_batch_discard (a picture is released when complete: the steady state of a pipeline).  For bench.py."""
     import time
     lib = L.lib()
     n = len(datas)
     ptrs = (C.c_char_p * n)(*[bytes(d) for d in datas])
     lens = (C.c_size_t * n)(*[len(d) for d in datas])
+    if not keep:
+        pics = (C.c_int64 * n)()
+        t0 = time.perf_counter()
+        L.check(lib.lh264_parse_batch_discard(ptrs, lens, n, threads, pics))
+        return time.perf_counter() - t0, int(sum(pics))
     outs = (C.c_void_p * n)()
     t0 = time.perf_counter()
     L.check(lib.lh264_parse_batch(ptrs, lens, n, threads, outs))
