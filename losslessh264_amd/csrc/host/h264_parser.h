@@ -164,7 +164,12 @@ class MainStreamWriter {
   void append_byte (uint8_t x);
   void append_bytes (const uint8_t* d, size_t n) { for (size_t i = 0; i < n; i++) append_byte (d[i]); }
   void emit_bit (uint32_t bit);
-  void emit_bits (uint32_t v, int n) { for (int i = n - 1; i >= 0; i--) emit_bit ((v >> i) & 1); }
+  void emit_bits (uint32_t v, int n) {           // n <= 32, MSB first
+    uint64_t acc = ((uint64_t)bits_ << n) | (n >= 32 ? (uint64_t)v : ((uint64_t)v & ((1ull << n) - 1)));
+    int k = n_bits_ + n;
+    while (k >= 8) { append_byte ((uint8_t) (acc >> (k - 8))); k -= 8; }
+    bits_ = (uint32_t) (acc & ((1u << k) - 1u)); n_bits_ = k;
+  }
   int bits_in_byte() const { return n_bits_; }
   void start_escape() { escaping_ = true; }
   void stop_escape();

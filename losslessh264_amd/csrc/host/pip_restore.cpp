@@ -18,11 +18,19 @@ enum { TAG_SKIP = 1, TAG_SKIP_END = 2, TAG_CBPL = 4, TAG_QPL = 6, TAG_MB_TYPE = 
        TAG_CRAC = 29, TAG_PADBYTE = 69, N_TAGS = 72 };
 
 // ---- DynProb, CS:87-115 -------------------------------------------------------------------------------------------------
+// floor (num / den) for num < 2^18, 2 <= den <= 516 by a reciprocal table (the division is a third of a decision's cost)
+struct RecipTable { uint32_t inv[520]; RecipTable() { inv[0] = inv[1] = 0; for (uint32_t d = 2; d < 520; d++) inv[d] = (uint32_t) (((1ull << 32) + d - 1) / d); } };
+inline uint8_t div_prob (uint32_t num, uint32_t den) {
+  static const RecipTable T;
+  uint32_t q = (uint32_t) (((uint64_t)num * T.inv[den]) >> 32);
+  if (q * den > num) q--;                            // ceil(2^32/den) overestimates by less than num/2^32 * ... : at most one too many
+  return (uint8_t)q;
+}
 struct DynProb {
   uint16_t c0 = 0, c1 = 0; uint8_t prob = 128;
   inline void update (int bit) {
     if (bit) c1++; else c0++;
-    prob = (uint8_t) ((256u * (c0 + 1u)) / (c0 + c1 + 2u));
+    prob = div_prob (256u * (c0 + 1u), c0 + c1 + 2u);
     if (c0 + c1 > 512) { c0 = (uint16_t) ((c0 + 1) >> 1); c1 = (uint16_t) ((c1 + 1) >> 1); }
   }
 };
@@ -46,8 +54,8 @@ struct BoolReader {
     int bit = 0;
     uint32_t r = split;
     if (value >= bigsplit) { r = range - split; value -= bigsplit; bit = 1; }
-    int shift = 0;
-    while (r < 128) { r <<= 1; shift++; }
+    const int shift = r >= 128 ? 0 : __builtin_clz (r) - 24;       // vpx_norm[r]
+    r <<= shift;
     range = r; value <<= shift; count -= shift;
     return bit;
   }
