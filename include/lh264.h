@@ -318,6 +318,18 @@ int lh264_pip_restore (const uint8_t* main_stream, size_t main_len, const uint8_
                        uint8_t* out, size_t out_cap, size_t* out_len);
 const char* lh264_restore_error (void);       /* message of the calling thread's last failed lh264_pip_restore */
 
+/* ---- single-file container: the default stream and the tagged streams in one file, or - flag VERBATIM - the
+ * input itself for streams the round trip cannot carry (I_PCM, damaged streams, syntax the front end does not parse), so that
+ * every input restores.  Layout: "LHPIP1\0\0", u32 flags, u32 n, n x {u32 stream id (0x7fffffff = default stream, else the
+ * tag id), u32 length}, the payloads in that order; little endian.  The reference has no counterpart (it writes one file per
+ * stream, h264dec.cpp:79-104, and aborts on what it cannot restore). */
+#define LH264_PIP_VERBATIM 1u
+size_t lh264_pip_pack_bound (size_t main_len, const size_t* tag_len, int n_tags);
+int lh264_pip_pack (const uint8_t* main_stream, size_t main_len, const uint8_t* const* tags, const size_t* tag_len, int n_tags,
+                    uint32_t flags, uint8_t* out, size_t out_cap, size_t* out_len);
+/* restore from a container: lh264_pip_restore on its streams, or a copy of the payload when it is VERBATIM */
+int lh264_pip_restore_file (const uint8_t* file, size_t len, uint8_t* out, size_t out_cap, size_t* out_len);
+
 /* ---- batches of independent streams on the host cores (streams are independent, one thread each) --
  * lh264_parse_batch: n Annex-B files -> n parsers (lh264_parser_feed_file each), `threads` worker threads (0 = one per
  * hardware thread).  parsers_out[i] is always a valid handle to destroy; its error text tells whether the stream parsed.

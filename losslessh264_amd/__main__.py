@@ -3,6 +3,10 @@
 
     python -m losslessh264_amd in.264  out.pip [out.yuv]    compress: out.pip = default stream, out.pip.<tag> = tagged streams
     python -m losslessh264_amd in.pip  out.264              restore the original bytes from in.pip + in.pip.<tag>
+    python -m losslessh264_amd in.264  out.lhp              compress into ONE file (LHPIP1 container, include/lh264.h); the result is
+                                                            restored and compared before it is written, and a stream the round trip
+                                                            cannot carry (I_PCM, damaged or unsupported syntax) is stored verbatim
+    python -m losslessh264_amd in.lhp  out.264              restore from the container
 
 Compress runs the host front end and the HIP context-index + coder kernels (needs the GPU); the optional YUV dump runs the
 HIP reconstruct kernel and writes the cropped I420 pictures like the reference's decoder.  Restore is host code.
@@ -12,6 +16,46 @@ import os
 import sys
 
 import numpy as np
+
+
+def compress_single(src, dst):
+    import losslessh264_amd as lh
+    data = open(src, "rb").read()
+    blob = None
+    why = ""
+    try:
+        frames, err, main = lh.parse_file(data)
+        if err:
+            why = err
+        elif frames:
+            ctx = lh.CtxSession([frames])
+            ctx.run()
+            coder = lh.CoderSession(ctx, hash_cap=1 << 18, out_cap=max(1 << 16, 2 * len(data)))
+            coder.run()
+            ctx.synchronize()
+            tags = coder.tags(0)
+            if lh.restore(main, tags) == data:
+                blob = lh.pack(main, tags)
+            else:
+                why = "the restored stream differs"
+        else:
+            why = "no picture"
+    except RuntimeError as e:
+        why = str(e)
+    if blob is None or len(blob) >= len(data) + 32:
+        blob = lh.pack(data, {}, lh.VERBATIM)
+        why = why or "no gain"
+    with open(dst, "wb") as f:
+        f.write(blob)
+    print("%s: %d bytes -> %d bytes (%.4f)%s" % (src, len(data), len(blob), len(blob) / max(1, len(data)), "  [verbatim: %s]" % why if why else ""))
+
+
+def restore_single(src, dst):
+    import losslessh264_amd as lh
+    out = lh.restore_file(open(src, "rb").read())
+    with open(dst, "wb") as f:
+        f.write(out)
+    print("%s -> %s: %d bytes" % (src, dst, len(out)))
 
 
 def compress(src, dst, yuv=None):
@@ -63,7 +107,11 @@ def main(argv):
     if len(argv) < 3:
         print(__doc__)
         return 2
-    if ".pip" in os.path.basename(argv[1]):      # as the reference decides (h264dec.cpp:167-173)
+    if argv[1].endswith(".lhp"):
+        restore_single(argv[1], argv[2])
+    elif argv[2].endswith(".lhp"):
+        compress_single(argv[1], argv[2])
+    elif ".pip" in os.path.basename(argv[1]):      # as the reference decides (h264dec.cpp:167-173)
         restore(argv[1], argv[2])
     else:
         compress(argv[1], argv[2], argv[3] if len(argv) > 3 else None)

@@ -224,6 +224,62 @@ int lh264_pip_restore (const uint8_t* main_stream, size_t main_len, const uint8_
   return LH264_OK;
 }
 const char* lh264_restore_error (void) { return g_restore_err.c_str(); }
+static void put32 (uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t) (v >> 8); p[2] = (uint8_t) (v >> 16); p[3] = (uint8_t) (v >> 24); }
+static uint32_t get32 (const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+static const char kPipMagic[8] = {'L', 'H', 'P', 'I', 'P', '1', 0, 0};
+size_t lh264_pip_pack_bound (size_t main_len, const size_t* tag_len, int n_tags) {
+  size_t n = 16 + 8 + main_len;
+  for (int t = 0; tag_len && t < n_tags; t++) n += 8 + tag_len[t];
+  return n;
+}
+int lh264_pip_pack (const uint8_t* main_stream, size_t main_len, const uint8_t* const* tags, const size_t* tag_len, int n_tags,
+                    uint32_t flags, uint8_t* out, size_t out_cap, size_t* out_len) {
+  if ((!main_stream && main_len) || !out_len || n_tags < 0 || (n_tags && (!tags || !tag_len))) return LH264_E_ARG;
+  int n = 1;
+  size_t total = main_len;
+  for (int t = 0; t < n_tags; t++) if (tags[t]) { n++; total += tag_len[t]; if (tag_len[t] > 0xffffffffull) return LH264_E_ARG; }
+  if (main_len > 0xffffffffull) return LH264_E_ARG;
+  const size_t need = 16 + 8 * (size_t)n + total;
+  *out_len = need;
+  if (!out || out_cap < need) return LH264_E_ARG;
+  memcpy (out, kPipMagic, 8); put32 (out + 8, flags); put32 (out + 12, (uint32_t)n);
+  uint8_t* h = out + 16; uint8_t* d = out + 16 + 8 * (size_t)n;
+  put32 (h, 0x7fffffffu); put32 (h + 4, (uint32_t)main_len); h += 8;
+  if (main_len) memcpy (d, main_stream, main_len);
+  d += main_len;
+  for (int t = 0; t < n_tags; t++) if (tags[t]) {
+      put32 (h, (uint32_t)t); put32 (h + 4, (uint32_t)tag_len[t]); h += 8;
+      if (tag_len[t]) memcpy (d, tags[t], tag_len[t]);
+      d += tag_len[t];
+    }
+  return LH264_OK;
+}
+int lh264_pip_restore_file (const uint8_t* file, size_t len, uint8_t* out, size_t out_cap, size_t* out_len) {
+  if (!file || !out_len) return LH264_E_ARG;
+  if (len < 16 || memcmp (file, kPipMagic, 8) != 0) { g_restore_err = "not a LHPIP1 container"; return LH264_E_UNSUPPORTED; }
+  const uint32_t flags = get32 (file + 8), n = get32 (file + 12);
+  if (n < 1 || (size_t)n > (len - 16) / 8) { g_restore_err = "corrupt container"; return LH264_E_UNSUPPORTED; }
+  const uint8_t* d = file + 16 + 8 * (size_t)n;
+  size_t left = len - 16 - 8 * (size_t)n;
+  const uint8_t* main_stream = nullptr; size_t main_len = 0;
+  const uint8_t* tags[72]; size_t tag_len[72];
+  for (int t = 0; t < 72; t++) { tags[t] = nullptr; tag_len[t] = 0; }
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t id = get32 (file + 16 + 8 * (size_t)i), ln = get32 (file + 20 + 8 * (size_t)i);
+    if (ln > left) { g_restore_err = "corrupt container"; return LH264_E_UNSUPPORTED; }
+    if (id == 0x7fffffffu) { main_stream = d; main_len = ln; }
+    else if (id < 72) { tags[id] = ln ? d : (const uint8_t*)""; tag_len[id] = ln; }
+    d += ln; left -= ln;
+  }
+  if (!main_stream && main_len == 0 && !(flags & LH264_PIP_VERBATIM)) main_stream = (const uint8_t*)"";
+  if (flags & LH264_PIP_VERBATIM) {
+    *out_len = main_len;
+    if (main_len > out_cap || (!out && main_len)) { g_restore_err = "output buffer too small"; return LH264_E_ARG; }
+    if (main_len) memcpy (out, main_stream, main_len);
+    return LH264_OK;
+  }
+  return lh264_pip_restore (main_stream, main_len, tags, tag_len, 72, out, out_cap, out_len);
+}
 int lh264_parse_batch (const uint8_t* const* data, const size_t* len, int n, int threads, lh264_parser_t** parsers_out) {
   if (!data || !len || !parsers_out || n < 0) return LH264_E_ARG;
   for (int i = 0; i < n; i++) parsers_out[i] = new lh264_parser();

@@ -65,3 +65,39 @@ def restore_batch(items, threads=0, out_cap=None):
         it.out, it.out_cap = C.addressof(buf), cap
     L.check(lib.lh264_pip_restore_batch(C.byref(arr), len(items), threads))
     return [keep[i][2].raw[:arr[i].out_len] if arr[i].status == 0 else None for i in range(len(items))]
+
+
+VERBATIM = 1
+
+
+def pack(main, tags, flags=0):
+    """default stream + tagged streams (or, with VERBATIM, the input itself as `main`) -> one LHPIP1 container (C ABI lh264_pip_pack)"""
+    lib = L.lib()
+    ptrs = (C.c_char_p * N_TAG_IDS)()
+    lens = (C.c_size_t * N_TAG_IDS)()
+    for t, b in tags.items():
+        if 0 <= t < N_TAG_IDS:
+            ptrs[t] = bytes(b)
+            lens[t] = len(b)
+    cap = lib.lh264_pip_pack_bound(len(main), lens, N_TAG_IDS)
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t(0)
+    L.check(lib.lh264_pip_pack(bytes(main), len(main), ptrs, lens, N_TAG_IDS, flags, out, cap, C.byref(n)))
+    return out.raw[:n.value]
+
+
+def restore_file(blob, size_hint=None):
+    """LHPIP1 container -> the original stream (C ABI lh264_pip_restore_file)"""
+    lib = L.lib()
+    cap = size_hint or (4 * len(blob) + 4096)
+    for _ in range(2):
+        out = C.create_string_buffer(cap)
+        n = C.c_size_t(0)
+        rc = lib.lh264_pip_restore_file(bytes(blob), len(blob), out, cap, C.byref(n))
+        if rc == 0:
+            return out.raw[:n.value]
+        if rc == -2 and n.value > cap:
+            cap = n.value
+            continue
+        break
+    raise RuntimeError("restore failed: " + lib.lh264_restore_error().decode())

@@ -107,3 +107,22 @@ def test_command_line_compress_and_restore(tmp_path):
     assert hashlib.sha1(open(yuv, "rb").read()).hexdigest() == sha[name]
     subprocess.check_call([sys.executable, "-m", "losslessh264_amd", pip, back], env=env, cwd=root)
     assert open(back, "rb").read() == open(src, "rb").read()
+
+
+def test_command_line_single_file_with_verbatim_fallback(tmp_path):
+    """`... in.264 out.lhp` / `... out.lhp back.264`: one container file; an I_PCM stream (which the round trip cannot carry, as in
+    the reference) is stored verbatim and still restores"""
+    import subprocess
+    import sys
+    root = os.path.dirname(golden_io.GOLDEN_DIR.rstrip("/")).rsplit("/tests", 1)[0]
+    env = dict(os.environ, PYTHONPATH=root)
+    for name, expect_gain in (("SVA_BA1_B.264", True), ("test_qcif_cabac.264", False), ("QCIF_2P_I_allIPCM.264", False)):
+        src = os.path.join(golden_io.GOLDEN_DIR, "streams", name)
+        lhp, back = str(tmp_path / (name + ".lhp")), str(tmp_path / (name + ".back"))
+        subprocess.check_call([sys.executable, "-m", "losslessh264_amd", src, lhp], env=env, cwd=root)
+        subprocess.check_call([sys.executable, "-m", "losslessh264_amd", lhp, back], env=env, cwd=root)
+        assert open(back, "rb").read() == open(src, "rb").read()
+        if expect_gain:
+            assert os.path.getsize(lhp) < os.path.getsize(src)
+        else:
+            assert os.path.getsize(lhp) <= os.path.getsize(src) + 24      # CABAC barely compresses: verbatim when there is no gain

@@ -88,3 +88,32 @@ def _corrupt_trials(rng, name):
         except RuntimeError:
             pass
     assert lh.restore(main, tags) == orig
+
+
+# ---- single-file container (row f3) ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["SVA_BA2_D.264", "test_qcif_cabac.264"])
+def test_single_file_container_round_trip(name):
+    main, tags = cli_fixture(name)
+    orig = open(os.path.join(STREAMS, name), "rb").read()
+    blob = lh.pack(main, tags)
+    assert blob[:6] == b"LHPIP1" and len(blob) == 16 + 8 * (1 + len(tags)) + len(main) + sum(len(b) for b in tags.values())
+    assert lh.restore_file(blob) == orig
+    vb = lh.pack(orig, {}, lh.VERBATIM)
+    assert len(vb) == len(orig) + 24 and lh.restore_file(vb) == orig
+
+
+def test_single_file_container_rejects_damage():
+    main, tags = cli_fixture("SVA_BA2_D.264")
+    blob = lh.pack(main, tags)
+    for bad in (b"", blob[:10], b"XXXXXXXX" + blob[8:], blob[:12] + b"\xff\xff\xff\x7f" + blob[16:], blob[:20] + b"\xff\xff\xff\x7f" + blob[24:]):
+        with pytest.raises(RuntimeError):
+            lh.restore_file(bad)
+    rng = np.random.default_rng(3)
+    for _ in range(10):                    # damaged payloads: an error or other bytes, never a crash
+        b = bytearray(blob)
+        for pos in rng.integers(16, len(b), 5):
+            b[pos] = int(rng.integers(0, 256))
+        try:
+            lh.restore_file(bytes(b))
+        except RuntimeError:
+            pass
