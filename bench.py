@@ -194,6 +194,8 @@ def main():
                                         "front_end_keep_all_MB_per_s": nb * stream_bytes / pk / 1e6,
                                         "restore_MB_per_s": nb * stream_bytes / rt / 1e6}
         coder_info["roundtrip"] = roundtrip
+        # everything the compress direction does on the device, run back to back: a1-a8 (the timed step) + a9/a10 (this stage)
+        coder_info["device_compress_a1_a10_MB_per_s"] = args.streams * stream_bytes / (dt / args.steps * 1e3 + c_ms) / 1e3
         del coder
 
     if rank == 0:

@@ -107,11 +107,13 @@ __device__ __forceinline__ void bc_finish (Bc& b, GLB uint8_t* out, uint32_t cap
 }
 
 #ifdef LH264_CODER_STAMP
-#define STAMP_FIELDS uint64_t st_t, st_acc[12];
+#define STAMP_FIELDS uint64_t st_t, st_acc[16];
+#define STAMP_COUNT(c, i, v) (c).st_acc[i] += (uint64_t) (v);
 #define STAMP(c, i) { const uint64_t st_n = __builtin_amdgcn_s_memtime(); (c).st_acc[i] += st_n - (c).st_t; (c).st_t = st_n; }
 #else
 #define STAMP_FIELDS
 #define STAMP(c, i)
+#define STAMP_COUNT(c, i, v)
 #endif
 // ---- the wave's coding context ---------------------------------------------------------------------------------------------
 struct Coder {
@@ -392,10 +394,14 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
       int maxrank = 0;
       for (unsigned long long b = __ballot (is_user && rank > 0); b; ) { maxrank++; b = __ballot (is_user && rank > maxrank); }
       uint32_t* cr = bcell + owner * 16;
+      STAMP_COUNT (c, 12, 1) STAMP_COUNT (c, 13, maxrank + 1)
+      { int mx = nd; for (int dd = 32; dd; dd >>= 1) mx = max (mx, __shfl_xor (mx, dd)); STAMP_COUNT (c, 14, mx) }
       for (int rnd = 0; rnd <= maxrank; rnd++) {
         if ((is_user && rank == rnd) || (rnd == 0 && !is_user)) {
+          uint32_t wn = row[0];                          // next word fetched ahead: the compiler may not move it across the stores below
           for (int t = 0; t < nd; t++) {
-            uint32_t w = row[t];
+            uint32_t w = wn;
+            wn = row[t + 1 < DL_STRIDE ? t + 1 : t];
             const int j = (int) (w & 0xffu);
             if (j != 0xff) {
               const uint32_t sv = cr[j];
@@ -446,9 +452,12 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
     // (4)
     {
       GLB uint8_t* o = c.out + (size_t)lane * c.cap;
+      { int mx = my_tot; for (int dd = 32; dd; dd >>= 1) mx = max (mx, __shfl_xor (mx, dd)); STAMP_COUNT (c, 15, mx) }
+      uint32_t wn = my_tot > 0 ? sorted[my_seg] : 0u;
       for (int q = 0; __ballot (q < my_tot); q++) {
         if (q < my_tot) {
-          const uint32_t w = sorted[my_seg + q];
+          const uint32_t w = wn;
+          if (q + 1 < my_tot) wn = sorted[my_seg + q + 1];
 #ifndef LH264_CODER_ABL_NOBC
           bc_write (c.bc, o, c.cap, (int) ((w >> 8) & 1u), (int) (w >> 24));
 #else
@@ -529,7 +538,7 @@ coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __
   c.cellv = 0; c.cur_key = 0; c.cur_slot = 0; c.have_cell = false; c.test_prob = 0; c.status = 0;
   c.bc.used = 0; c.bc.pos = 0; c.bc.low = 0; c.bc.range = 255; c.bc.count = -24; c.bc.ffrun = 0; c.bc.pending = -1; c.bc.last = 0;
 #ifdef LH264_CODER_STAMP
-  c.st_t = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 12; i++) c.st_acc[i] = 0;
+  c.st_t = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 16; i++) c.st_acc[i] = 0;
 #endif
   const int lane = c.lane;
   // One loop, one copy of the coder: fill the queue from the stream's symbol sources (host list of macroblock k, with the
@@ -591,7 +600,7 @@ coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __
   cell_flush (c);
   STAMP (c, 6)
 #ifdef LH264_CODER_STAMP
-  if (c.lane == 0) { GLB uint64_t* dbg = (GLB uint64_t*) (c.out + (size_t)39 * c.cap); for (int i = 0; i < 12; i++) dbg[i] = c.st_acc[i]; }
+  if (c.lane == 0) { GLB uint64_t* dbg = (GLB uint64_t*) (c.out + (size_t)39 * c.cap); for (int i = 0; i < 16; i++) dbg[i] = c.st_acc[i]; }
 #endif
   GLB uint32_t* lens = glb<uint32_t> (S->out_len_dev);
   if (c.lane < LH264_N_TAG_SLOTS) {

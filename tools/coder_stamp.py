@@ -14,7 +14,9 @@ coder = lh.CoderSession(ctx)
 ctx.run(); coder.run(); ctx.synchronize()
 out = coder.d_out.cpu().numpy().reshape(streams, L.N_TAG_SLOTS, coder.out_cap)
 names = ["fill", "binarise", "owner+rank", "probe+fetch", "serial execute", "writeback", "tail", "touch+raw bits", "cell rows", "tag scans", "scatter", "bool coders"]
-acc = out[:, 39, :96].copy().view(np.uint64).astype(np.float64)     # [streams][12]
-tot = acc.sum(axis=1).mean()
+acc = out[:, 39, :128].copy().view(np.uint64).astype(np.float64)     # [streams][16]
+tot = acc[:, :12].sum(axis=1).mean()
 for i, n in enumerate(names):
     print("%-16s %6.1f %%" % (n, 100 * acc[:, i].mean() / tot))
+nb = acc[:, 12].mean()
+print("parallel batches/stream %.0f  rounds/batch %.2f  max decisions of a symbol/batch %.1f  longest tag list/batch %.1f" % (nb, acc[:, 13].mean() / nb, acc[:, 14].mean() / nb, acc[:, 15].mean() / nb))
