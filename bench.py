@@ -65,6 +65,32 @@ def cpu_baseline(frames, stream_bytes, seconds):
     return reps * stream_bytes / dt / 1e6, reps, dt
 
 
+def reference_cli_baseline(stream, stream_bytes):
+    """the unmodified reference's console application (oracle/_ref/h264dec, built in the build container by oracle/Makefile and
+    shipped like our own .so) compressing the bench stream once on this box: its whole pipeline (parse + reconstruct + model +
+    coder), one core.  In-call time from its own 'decode time' line; the wall time includes ~10 s of start-up (8.8 GB of tables)."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "h264dec")
+    if not os.path.exists(exe):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, stream, os.path.join(d, "o.pip")], cwd=d, capture_output=True, timeout=240)
+            wall = time.perf_counter() - t0
+            m = re.search(r"decode time:\s*([0-9.]+) sec", r.stdout.decode(errors="replace") + r.stderr.decode(errors="replace"))
+            size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("o.pip"))
+        if r.returncode != 0 or not m:
+            return None
+        sec = float(m.group(1))
+        return {"value": stream_bytes / sec / 1e6, "unit": "MB/s", "cores": 1, "kind": "reference",
+                "sample": "oracle/_ref/h264dec BA_MW_D.264 -> .pip once: whole pipeline, in-call %.3f s (wall %.1f s with start-up), %d bytes written" % (sec, wall, size)}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +245,9 @@ def main():
             v, reps, secs = cpu_baseline(frames, stream_bytes, args.cpu_seconds)
             out["cpu_baseline"] = {"value": v, "unit": "MB/s", "cores": 1, "kind": "port",
                                    "sample": "oracle (C restatement of rows a1-a8) over BA_MW_D.264 x %d passes, %.1f s, 1 thread" % (reps, secs)}
+            ref = reference_cli_baseline(os.path.join(ROOT, "tests", "golden", "streams", "BA_MW_D.264"), stream_bytes)
+            if ref is not None:
+                out["cpu_baseline"]["reference_cli"] = ref
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
