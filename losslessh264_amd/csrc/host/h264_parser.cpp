@@ -313,7 +313,7 @@ struct Parser::Impl {
         }
       }
     }
-    if (P.cabac && st != 2) sh.cabac_init_idc = br.ue();
+    if (P.cabac && st != 2) { const uint32_t ci = br.ue(); sh.cabac_init_idc = (int) (ci & 3); if (ci > 2) { fail ("cabac_init_idc out of range"); return false; } }
     sh.slice_qp = P.pic_init_qp + br.se();
     if (P.deblocking_control) {
       sh.deblock_idc = br.ue();

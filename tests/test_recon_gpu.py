@@ -131,6 +131,27 @@ def test_parser_to_gpu_sha1():
         assert h.hexdigest() == sha[name], name
 
 
+def test_big_geometries_match_oracle():
+    """BASELINE.json configs[2] / configs[3] geometries: 720p all-intra with 4 slices per picture and 1080p I/P, encoded by the
+    reference's encoder from a synthetic pattern (tests/golden/make_synth_streams.py): host front end -> HIP reconstruct, every
+    padded plane against the oracle"""
+    import os
+    import losslessh264_amd as lh
+    for name in ("syn720p_allI_4slices.264", "syn1080p_IP.264"):
+        frames, err = lh.parse_stream(open(os.path.join(golden_io.GOLDEN_DIR, "streams", name), "rb").read())
+        assert err == "" and len(frames) == 2
+        sess = lh.ReconSession([frames])
+        sess.run(); sess.synchronize()
+        pics = {}
+        for i, f in enumerate(frames):
+            dst = O.HostPic(f.mb_w, f.mb_h)
+            O.recon_frame(f.mbs, f.coeffs, f.slices, dst, [pics[r] for r in f.ref_ids], 0)
+            pics[f.id] = dst
+            got = sess.picture(0, i, padded=True)
+            for p in range(3):
+                assert np.array_equal(got[p], dst.padded_plane(p)), (name, i, p)
+
+
 def test_chain_with_resolution_change():
     """frames of different sizes in one chain (the row cursor of the pipelined wavefront crosses pictures of different
     heights; a new intra picture starts each segment, as after an SPS change)"""
