@@ -180,7 +180,7 @@ int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_fi
   if (lh264_device_count() <= 0) return fail (LH264_E_NODEVICE, "no HIP device visible");
   if (!jobs_dev || !chain_first_dev || !streams_dev || n_chains < 0) return fail (LH264_E_ARG, "bad argument");
   if (n_chains == 0) return LH264_OK;
-  hipLaunchKernelGGL (lh264::coder_chain_kernel, dim3 (n_chains), dim3 (64), 0, (hipStream_t)stream, jobs_dev, chain_first_dev, streams_dev, n_chains);
+  hipLaunchKernelGGL (lh264::coder_chain_kernel, dim3 (n_chains), dim3 (128), 0, (hipStream_t)stream, jobs_dev, chain_first_dev, streams_dev, n_chains);
   HIPCHK (hipGetLastError());
   return LH264_OK;
 }

@@ -115,6 +115,18 @@ __device__ __forceinline__ void bc_finish (Bc& b, GLB uint8_t* out, uint32_t cap
 #define STAMP(c, i)
 #define STAMP_COUNT(c, i, v)
 #endif
+// ---- what the symbol wave hands to the coding wave: a batch's decisions, probabilities resolved, sorted by tag --------------------
+#ifndef LH264_CODER_BUFS
+#define LH264_CODER_BUFS 1      // 2: one more batch in flight, 14 KB more LDS per stream (measured: no faster, fewer streams per CU)
+#endif
+struct Handoff {
+  uint32_t sorted[LH264_CODER_BUFS][64 * 56];   // [buffer][decision words: bit 8 the bit, bits 24..31 the probability]
+  uint32_t segtot[LH264_CODER_BUFS][64];        // [buffer][tag slot]: first word | number of words << 16
+  uint32_t touch[LH264_CODER_BUFS][2];          // [buffer]: tag slots whose stream comes into existence with this batch (64-bit mask)
+  int full[LH264_CODER_BUFS];    // buffer handed over, not yet coded
+  int done;                      // no more batches; `pstatus` is final
+  int pstatus;
+};
 // ---- the wave's coding context ---------------------------------------------------------------------------------------------
 struct Coder {
   GLB uint32_t* keys; GLB uint32_t* cells; uint32_t mask;
@@ -126,6 +138,7 @@ struct Coder {
   int status;
   Bc bc;                   // this lane's tag
   STAMP_FIELDS
+  Handoff* H; int buf;        // hand-off buffers (LDS) and the one to fill next
 };
 
 __device__ __forceinline__ int tag_slot (int tag) { return tag == 69 ? 34 : tag; }
@@ -279,13 +292,11 @@ __device__ __forceinline__ uint32_t build_symbol (DList& d, uint32_t prior, int 
   }
 }
 
-// one decision: adaptive update of the cell in hand (or of TEST_PROB), then it goes to the lane owning its tag
-__device__ __forceinline__ void decide (Coder& c, uint32_t w) {
+// one decision on the serial path: adaptive update of the cell in hand (or of TEST_PROB); the word, with the probability it
+// is coded with, goes to its tag's list (lane t keeps the write position of tag slot t)
+__device__ __forceinline__ void decide (Coder& c, uint32_t w, uint32_t* out, int& my_at) {
   const int j = (int) (w & 0xffu), bit = (int) ((w >> 8) & 1u), tag = (int) ((w >> 16) & 0xffu);
   int prob;
-#ifdef LH264_CODER_ABL_NODP
-  prob = 128 + (j & 1);
-#else
   if (j == 0xff) { prob = dp_prob (c.test_prob); c.test_prob = dp_update (c.test_prob, bit); }
   else {
     const uint32_t s = (uint32_t)__builtin_amdgcn_readlane ((int)c.cellv, j);
@@ -293,13 +304,7 @@ __device__ __forceinline__ void decide (Coder& c, uint32_t w) {
     const uint32_t ns = dp_update (s, bit);
     if (c.lane == j) c.cellv = ns;
   }
-#endif
-  const int slot = tag_slot (tag);
-#ifndef LH264_CODER_ABL_NOBC
-  if (c.lane == slot) bc_write (c.bc, c.out + (size_t)slot * c.cap, c.cap, bit, prob);
-#else
-  if (c.lane == slot) c.bc.low += (uint32_t) (prob + bit);
-#endif
+  if (c.lane == tag_slot (tag)) { out[my_at] = (w & 0x00ffffffu) | ((uint32_t)prob << 24); my_at++; }
 }
 
 // Code a batch of up to 64 symbols held one per lane (sym = the 8-byte record).  Binarisation and memory latency are paid
@@ -307,8 +312,7 @@ __device__ __forceinline__ void decide (Coder& c, uint32_t w) {
 // fetches it into the wave's LDS rows, all in parallel; the decisions are then executed strictly in order, a cell shared by
 // several symbols of the batch living in the row of the first of them; cells not found (new priors) and priors spanning
 // several cells go to the table serially.
-__device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, uint32_t* bcell /* LDS [64][16] */, uint32_t* dl /* LDS [64][DL_STRIDE] */,
-                                            uint32_t* sorted /* LDS [64 * DL_STRIDE] */) {
+__device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, uint32_t* bcell /* LDS [64][16] */, uint32_t* dl /* LDS [64][DL_STRIDE] */) {
   const int lane = c.lane;
   const uint32_t prior = (uint32_t)sym, hi = (uint32_t) (sym >> 32);
   DList d; d.row = dl + lane * DL_STRIDE; d.n = 0; d.raw = 0ull; d.sw = false;
@@ -359,12 +363,13 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
   const bool is_user = lane < count && key != 0u;
   if (!__ballot (d.sw || nd > DL_STRIDE || (is_user && !((valid >> owner) & 1ull)))) {
     uint32_t* row = dl + lane * DL_STRIDE;
-    {                                                  // a stream exists once one of its symbols was billed (EXP tags)
+    unsigned long long tmask = 0ull;                     // a stream exists once one of its symbols was billed (EXP tags)
+    {
       unsigned long long tl = __ballot (touch >= 0);
       while (tl) {
         const int i = __ffsll ((long long)tl) - 1;
         const int ti = __builtin_amdgcn_readlane (touch, i);
-        touch_tag (c, ti);
+        tmask |= 1ull << tag_slot (ti);
         tl &= ~__ballot (touch == ti);
       }
     }
@@ -439,6 +444,19 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
       }
     }
     STAMP (c, 9)
+    // the cell rows are final: back to the table while the words are sorted
+    if (key != 0u && owner == lane && ((valid >> lane) & 1ull)) {
+      GLB u32x4* dst = (GLB u32x4*) (c.cells + (size_t)slot * 16);
+      const u32x4* src = (const u32x4*) (bcell + lane * 16);
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    }
+    // (4) hand the sorted words to the coding wave
+    Handoff& H = *c.H;
+    const int buf = c.buf;
+    { volatile int* f = H.full; while (f[buf]) __builtin_amdgcn_s_sleep (1); }
+    asm volatile ("" ::: "memory");
+    STAMP (c, 11)
+    uint32_t* sorted = H.sorted[buf];
     for (int t = 0; t < nd; t++) {
       const uint32_t w = row[t];
       const int sl = tag_slot ((int) ((w >> 16) & 0xffu));
@@ -446,44 +464,44 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
       if (sl == s0) at = b0++; else if (sl == s1) at = b1++; else if (sl == s2) at = b2++; else at = b3++;
       sorted[at] = w;
     }
+    H.segtot[buf][lane] = (uint32_t)my_seg | ((uint32_t)my_tot << 16);
+    if (lane == 0) { H.touch[buf][0] = (uint32_t)tmask; H.touch[buf][1] = (uint32_t) (tmask >> 32); }
     asm volatile ("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) { volatile int* f = H.full; f[buf] = 1; }
+    c.buf = (buf + 1) % LH264_CODER_BUFS;
     STAMP (c, 10)
-    // (4)
-    {
-      GLB uint8_t* o = c.out + (size_t)lane * c.cap;
-      { int mx = my_tot; for (int dd = 32; dd; dd >>= 1) mx = max (mx, __shfl_xor (mx, dd)); STAMP_COUNT (c, 15, mx) }
-      uint32_t wn = my_tot > 0 ? sorted[my_seg] : 0u;
-      for (int q = 0; __ballot (q < my_tot); q++) {
-        if (q < my_tot) {
-          const uint32_t w = wn;
-          if (q + 1 < my_tot) wn = sorted[my_seg + q + 1];
-#ifndef LH264_CODER_ABL_NOBC
-          bc_write (c.bc, o, c.cap, (int) ((w >> 8) & 1u), (int) (w >> 24));
-#else
-          c.bc.low += w >> 24;
-#endif
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    STAMP (c, 11)
-    if (key != 0u && owner == lane && ((valid >> lane) & 1ull)) {
-      GLB u32x4* dst = (GLB u32x4*) (c.cells + (size_t)slot * 16);
-      const u32x4* src = (const u32x4*) (bcell + lane * 16);
-      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
-    }
-    __builtin_amdgcn_wave_barrier();
-    STAMP (c, 5)
     return;
   }
 #endif
+  // ---- the serial way (a tree prior leaves its first cell, or a cell was not found by the parallel probe) ----------------------
+  // first the size of every tag's list (lane t counts tag slot t), then the decisions one after the other, each word going to
+  // its tag's list with the probability it is coded with
+  Handoff& H = *c.H;
+  const int buf = c.buf;
+  int my_cnt = 0;
+  unsigned long long tmask = 0ull;
+  for (int i = 0; i < count; i++) {
+    const int ni = __builtin_amdgcn_readlane (nd, i);
+    const int ti = __builtin_amdgcn_readlane (touch, i);
+    if (ti >= 0) tmask |= 1ull << tag_slot (ti);
+    const uint32_t words = lane < ni ? dl[i * DL_STRIDE + lane] : 0u;
+    for (int t = 0; t < ni; t++) {
+      const uint32_t w = (uint32_t)__builtin_amdgcn_readlane ((int)words, t);
+      if (w & 0x80000000u) t++;
+      else if (lane == tag_slot ((int) ((w >> 16) & 0xffu))) my_cnt++;
+    }
+  }
+  const int my_seg = wave_scan_add (my_cnt) - my_cnt;
+  int my_at = my_seg;
+  { volatile int* f = H.full; while (f[buf]) __builtin_amdgcn_s_sleep (1); }
+  asm volatile ("" ::: "memory");
+  uint32_t* sorted = H.sorted[buf];
   for (int i = 0; i < count; i++) {
     const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane ((int)key, i);
     const int r = __builtin_amdgcn_readlane (owner, i);
     const int ni = __builtin_amdgcn_readlane (nd, i);
-    const int ti = __builtin_amdgcn_readlane (touch, i);
-    if (ti >= 0) touch_tag (c, ti);
     const uint32_t words = lane < ni ? dl[i * DL_STRIDE + lane] : 0u;      // the symbol's decisions, one per lane
     if (ki) {
       if ((valid >> r) & 1ull) c.cellv = lane < 16 ? bcell[r * 16 + lane] : 0u;
@@ -504,12 +522,18 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
         if (in_row) { if (lane < 16) bcell[r * 16 + lane] = c.cellv; in_row = false; c.have_cell = false; }
         cell_get (c, k2 - 1u);      // (writes a previous out-of-row cell back first)
         t++;
-      } else decide (c, w);
+      } else decide (c, w, sorted, my_at);
     }
     if (in_row) { if (lane < 16) bcell[r * 16 + lane] = c.cellv; }
     else cell_flush (c);
   }
+  H.segtot[buf][lane] = (uint32_t)my_seg | ((uint32_t)my_cnt << 16);
+  if (lane == 0) { H.touch[buf][0] = (uint32_t)tmask; H.touch[buf][1] = (uint32_t) (tmask >> 32); }
+  asm volatile ("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) { volatile int* f = H.full; f[buf] = 1; }
+  c.buf = (buf + 1) % LH264_CODER_BUFS;
   STAMP (c, 4)
   // write the rows back
   if (key != 0u && owner == lane && ((valid >> lane) & 1ull)) {
@@ -521,22 +545,80 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
   STAMP (c, 5)
 }
 
-__global__ void __launch_bounds__ (64)
+// Two waves per stream.  Wave 0 turns symbols into decisions with their probabilities (everything adaptive), wave 1 owns the 35
+// bool coders (lane t = tag slot t) and codes the lists wave 0 hands over through an LDS buffer: while one batch is being
+// coded the next one is being prepared (wave 0 needs the buffer again only when it has sorted the next batch).
+__global__ void __launch_bounds__ (128)
 coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __restrict__ chain_first,
                     const lh264_code_stream_t* __restrict__ streams, int n_chains) {
   __shared__ uint32_t bcell[64 * 16];
   __shared__ uint32_t dl[64 * DL_STRIDE];
-  __shared__ uint32_t sorted[64 * DL_STRIDE];
+  __shared__ Handoff H;
   __shared__ uint64_t queue[128];
   const int chain = blockIdx.x;
   if (chain >= n_chains) return;
   const lh264_code_stream_t* S = streams + chain;
+  const int wave = (int)threadIdx.x >> 6;
+  if (threadIdx.x < LH264_CODER_BUFS) { H.full[threadIdx.x] = 0; }
+  if (threadIdx.x == 0) { H.done = 0; H.pstatus = 0; }
+  __syncthreads();
+  if (wave == 1) {
+    // ---- the coding wave ---------------------------------------------------------------------------------------------------
+    const int lane = (int)threadIdx.x & 63;
+    GLB uint8_t* out = glb<uint8_t> (S->out_dev);
+    const uint32_t cap = S->out_cap;
+    GLB uint8_t* o = out + (size_t)lane * cap;
+    Bc bc;
+    bc.used = 0; bc.pos = 0; bc.low = 0; bc.range = 255; bc.count = -24; bc.ffrun = 0; bc.pending = -1; bc.last = 0;
+    volatile int* full = H.full;
+    volatile int* done = &H.done;
+    int buf = 0;
+    for (;;) {
+      while (!full[buf] && !*done) __builtin_amdgcn_s_sleep (1);
+      if (!full[buf]) {                                 // done was seen: a batch handed over before it must still be coded
+        __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+        if (!full[buf]) break;
+      }
+      __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+      asm volatile ("" ::: "memory");
+      const uint32_t st = H.segtot[buf][lane];
+      const int seg = (int) (st & 0xffffu), tot = (int) (st >> 16);
+      const unsigned long long tm = (unsigned long long)H.touch[buf][0] | ((unsigned long long)H.touch[buf][1] << 32);
+      if (((tm >> lane) & 1ull) && !bc.used) { bc.low = 0; bc.range = 255; bc.count = -24; bc.pos = 0; bc.ffrun = 0; bc.pending = -1; bc.used = 1; bc.last = 0; }
+      const uint32_t* sorted = H.sorted[buf];
+      uint32_t wn = tot > 0 ? sorted[seg] : 0u;
+      for (int q = 0; __ballot (q < tot); q++) {
+        if (q < tot) {
+          const uint32_t w = wn;
+          if (q + 1 < tot) wn = sorted[seg + q + 1];
+#ifndef LH264_CODER_ABL_NOBC
+          bc_write (bc, o, cap, (int) ((w >> 8) & 1u), (int) (w >> 24));
+#else
+          bc.low += w >> 24;
+#endif
+        }
+      }
+      asm volatile ("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) full[buf] = 0;
+      buf = (buf + 1) % LH264_CODER_BUFS;
+    }
+    GLB uint32_t* lens = glb<uint32_t> (S->out_len_dev);
+    if (lane < LH264_N_TAG_SLOTS) {
+      if (bc.used) bc_finish (bc, o, cap);
+      lens[lane] = bc.used ? bc.pos : 0u;
+    }
+    const unsigned long long over = __ballot (lane < LH264_N_TAG_SLOTS && bc.used && bc.pos > cap);
+    if (lane == 0) lens[LH264_N_TAG_SLOTS] = (uint32_t) (H.pstatus | (over ? 4 : 0));
+    return;
+  }
+  // ---- the symbol wave -------------------------------------------------------------------------------------------------------
   Coder c;
   c.keys = glb<uint32_t> (S->hash_keys_dev); c.cells = glb<uint32_t> (S->hash_cells_dev); c.mask = S->hash_cap - 1u;
   c.out = glb<uint8_t> (S->out_dev); c.cap = S->out_cap;
   c.lane = (int)threadIdx.x;
   c.cellv = 0; c.cur_key = 0; c.cur_slot = 0; c.have_cell = false; c.test_prob = 0; c.status = 0;
-  c.bc.used = 0; c.bc.pos = 0; c.bc.low = 0; c.bc.range = 255; c.bc.count = -24; c.bc.ffrun = 0; c.bc.pending = -1; c.bc.last = 0;
+  c.H = &H; c.buf = 0;
 #ifdef LH264_CODER_STAMP
   c.st_t = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 16; i++) c.st_acc[i] = 0;
 #endif
@@ -592,7 +674,7 @@ coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __
     const uint64_t sym = lane < m ? queue[lane] : 0ull;
     const uint64_t mv = queue[64 + lane];
     __builtin_amdgcn_wave_barrier();
-    code_batch (c, sym, m, bcell, dl, sorted);
+    code_batch (c, sym, m, bcell, dl);
     if (qn > 64) queue[lane] = mv;                   // what is left moves to the front
     qn -= m;
     __builtin_amdgcn_wave_barrier();
@@ -602,13 +684,10 @@ coder_chain_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __
 #ifdef LH264_CODER_STAMP
   if (c.lane == 0) { GLB uint64_t* dbg = (GLB uint64_t*) (c.out + (size_t)39 * c.cap); for (int i = 0; i < 16; i++) dbg[i] = c.st_acc[i]; }
 #endif
-  GLB uint32_t* lens = glb<uint32_t> (S->out_len_dev);
-  if (c.lane < LH264_N_TAG_SLOTS) {
-    if (c.bc.used) bc_finish (c.bc, c.out + (size_t)c.lane * c.cap, c.cap);
-    lens[c.lane] = c.bc.used ? c.bc.pos : 0u;
-  }
-  const unsigned long long over = __ballot (c.lane < LH264_N_TAG_SLOTS && c.bc.used && c.bc.pos > c.cap);
-  if (c.lane == 0) lens[LH264_N_TAG_SLOTS] = (uint32_t) (c.status | (over ? 4 : 0));
+  if (c.lane == 0) H.pstatus = c.status;
+  asm volatile ("" ::: "memory");
+  __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+  if (c.lane == 0) { volatile int* dn = &H.done; *dn = 1; }
 }
 
 }  // namespace lh264
