@@ -401,6 +401,15 @@ __device__ __forceinline__ void code_batch (Coder& c, uint64_t sym, int count, u
       uint32_t* cr = bcell + owner * 16;
       STAMP_COUNT (c, 12, 1) STAMP_COUNT (c, 13, maxrank + 1)
       { int mx = nd; for (int dd = 32; dd; dd >>= 1) mx = max (mx, __shfl_xor (mx, dd)); STAMP_COUNT (c, 14, mx) }
+#ifdef LH264_CODER_STAMP
+      {   // diagnostic: loop trips of the round scheme against the longest per-row chain (what an owner-driven pass would take)
+        int ideal = 0;
+        for (int j = 0; j < count; j++) { const int oj = __builtin_amdgcn_readlane (owner, j), nj = __builtin_amdgcn_readlane (nd, j); const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane ((int)key, j); if (kj && lane == oj) ideal += nj; }
+        for (int dd = 32; dd; dd >>= 1) ideal = max (ideal, __shfl_xor (ideal, dd));
+        STAMP_COUNT (c, 6, ideal)
+        for (int rnd = 0; rnd <= maxrank; rnd++) { int mx = ((is_user && rank == rnd) || (rnd == 0 && !is_user)) ? nd : 0; for (int dd = 32; dd; dd >>= 1) mx = max (mx, __shfl_xor (mx, dd)); STAMP_COUNT (c, 15, mx) }
+      }
+#endif
       for (int rnd = 0; rnd <= maxrank; rnd++) {
         if ((is_user && rank == rnd) || (rnd == 0 && !is_user)) {
           uint32_t wn = row[0];                          // next word fetched ahead: the compiler may not move it across the stores below
