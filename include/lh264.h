@@ -330,6 +330,21 @@ int lh264_pip_pack (const uint8_t* main_stream, size_t main_len, const uint8_t* 
 /* restore from a container: lh264_pip_restore on its streams, or a copy of the payload when it is VERBATIM */
 int lh264_pip_restore_file (const uint8_t* file, size_t len, uint8_t* out, size_t out_cap, size_t* out_len);
 
+/* ---- the whole compress direction behind one call (host orchestration in C++; what the Python sessions of this repository do)
+ * n independent Annex-B files -> per stream the default stream and the tagged streams, exactly the files the reference's console
+ * application writes (h264dec.cpp:79-121): host front end on `threads` host threads (0 = all), one lh264_ctx_index_chains and
+ * one lh264_code_chains launch per sub-batch on the current device, results copied back.  Every out[i] is a handle to free;
+ * lh264_compressed_status tells whether stream i compressed (LH264_OK) or why not (LH264_E_UNSUPPORTED: syntax the front end
+ * does not parse; LH264_E_HIP ...), lh264_compressed_error gives the text. */
+typedef struct lh264_compressed lh264_compressed_t;
+int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, int threads, lh264_compressed_t** out);
+int lh264_compressed_status (const lh264_compressed_t* c);
+const char* lh264_compressed_error (const lh264_compressed_t* c);
+const uint8_t* lh264_compressed_main (const lh264_compressed_t* c, size_t* len);
+const uint8_t* lh264_compressed_tag (const lh264_compressed_t* c, int tag, size_t* len);     /* NULL: the stream does not exist */
+int lh264_compressed_pictures (const lh264_compressed_t* c);
+void lh264_compressed_free (lh264_compressed_t* c);
+
 /* ---- batches of independent streams on the host cores (streams are independent, one thread each) --
  * lh264_parse_batch: n Annex-B files -> n parsers (lh264_parser_feed_file each), `threads` worker threads (0 = one per
  * hardware thread).  parsers_out[i] is always a valid handle to destroy; its error text tells whether the stream parsed.

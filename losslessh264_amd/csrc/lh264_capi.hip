@@ -11,6 +11,7 @@
 #include <vector>
 #include "../../include/lh264.h"
 #include "host/h264_parser.h"
+#include "host/capi_internal.h"
 #include "host/pip_restore.h"
 
 namespace lh264 {
@@ -203,7 +204,6 @@ double lh264_time_recon_chains (const lh264_frame_job_t* jobs_dev, const int32_t
 }
 
 // ---- host front end ------------------------------------------------------------------------------------------------
-struct lh264_parser { lh264host::Parser p; };
 lh264_parser_t* lh264_parser_create (void) { return new lh264_parser(); }
 void lh264_parser_destroy (lh264_parser_t* p) { delete p; }
 int lh264_parser_feed (lh264_parser_t* p, const uint8_t* data, size_t len, int flush) {

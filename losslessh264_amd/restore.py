@@ -101,3 +101,29 @@ def restore_file(blob, size_hint=None):
             continue
         break
     raise RuntimeError("restore failed: " + lib.lh264_restore_error().decode())
+
+
+def compress_batch(datas, threads=0):
+    """the whole compress direction behind one C call (lh264_compress_batch): list of Annex-B byte strings ->
+    list of (main bytes, {tag: bytes}, error text or None)"""
+    lib = L.lib()
+    n = len(datas)
+    ptrs = (C.c_char_p * n)(*[bytes(d) for d in datas])
+    lens = (C.c_size_t * n)(*[len(d) for d in datas])
+    outs = (C.c_void_p * n)()
+    L.check(lib.lh264_compress_batch(ptrs, lens, n, threads, outs))
+    res = []
+    for i in range(n):
+        h = outs[i]
+        ln = C.c_size_t(0)
+        p = lib.lh264_compressed_main(h, C.byref(ln))
+        main = C.string_at(p, ln.value) if ln.value else b""
+        tags = {}
+        for t in range(N_TAG_IDS):
+            p = lib.lh264_compressed_tag(h, t, C.byref(ln))
+            if p:
+                tags[t] = C.string_at(p, ln.value)
+        err = None if lib.lh264_compressed_status(h) == 0 else lib.lh264_compressed_error(h).decode()
+        res.append((main, tags, err))
+        lib.lh264_compressed_free(h)
+    return res

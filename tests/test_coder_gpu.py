@@ -126,3 +126,57 @@ def test_command_line_single_file_with_verbatim_fallback(tmp_path):
             assert os.path.getsize(lhp) < os.path.getsize(src)
         else:
             assert os.path.getsize(lhp) <= os.path.getsize(src) + 24      # CABAC barely compresses: verbatim when there is no gain
+
+
+# ---- the compress direction behind one C call, and the C++ console application on top of it -----------------------------------
+def test_compress_batch_c_api_equals_reference_cli():
+    """lh264_compress_batch (host orchestration in C++: parse threads, staging, ctx + coder launches, download) on all fixture
+    streams at once: default stream and every tagged stream equal the reference console application's files"""
+    import losslessh264_amd as lh
+    datas = [open(os.path.join(golden_io.GOLDEN_DIR, "streams", n), "rb").read() for n in CLI]
+    res = lh.compress_batch(datas)
+    for name, data, (main, tags, err) in zip(CLI, datas, res):
+        assert err is None, (name, err)
+        z = np.load(os.path.join(golden_io.GOLDEN_DIR, "cli_" + name + ".npz"))
+        assert main == z["main"].tobytes(), name
+        ref = {int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")}
+        assert tags == ref, (name, sorted(tags), sorted(ref))
+        assert lh.restore(main, tags) == data, name
+
+
+def test_cpp_console_application(tmp_path):
+    """losslessh264_amd/lh264dec (C++, built by __graft_entry__.build against include/*.h): the reference console application's
+    calling convention and files, the YUV dump, the single-file mode with its verbatim fallback, and the batch mode"""
+    import hashlib
+    import json
+    import subprocess
+    root = os.path.dirname(golden_io.GOLDEN_DIR.rstrip("/")).rsplit("/tests", 1)[0]
+    exe = os.path.join(root, "losslessh264_amd", "lh264dec")
+    assert os.path.exists(exe), "lh264dec not built"
+    name = "SVA_BA1_B.264"
+    src = os.path.join(golden_io.GOLDEN_DIR, "streams", name)
+    pip, yuv, back = str(tmp_path / "out.pip"), str(tmp_path / "out.yuv"), str(tmp_path / "back.264")
+    subprocess.check_call([exe, src, pip, yuv], timeout=300)
+    z = np.load(os.path.join(golden_io.GOLDEN_DIR, "cli_" + name + ".npz"))
+    assert open(pip, "rb").read() == z["main"].tobytes()
+    written = sorted(int(p.rsplit(".", 1)[1]) for p in glob.glob(pip + ".*"))
+    assert written == sorted(int(k[4:]) for k in z.files if k.startswith("tag_"))
+    for t in written:
+        assert open("%s.%d" % (pip, t), "rb").read() == z["tag_%d" % t].tobytes(), t
+    sha = json.load(open(os.path.join(golden_io.GOLDEN_DIR, "decoder_sha1.json")))
+    assert hashlib.sha1(open(yuv, "rb").read()).hexdigest() == sha[name]
+    subprocess.check_call([exe, pip, back], timeout=300)
+    assert open(back, "rb").read() == open(src, "rb").read()
+    # one container per stream, several streams in one call; the I_PCM stream falls back to verbatim
+    names = ["SVA_BA2_D.264", "tibby8x8cavlc.264", "QCIF_2P_I_allIPCM.264", "test_qcif_cabac.264"]
+    outd = tmp_path / "batch"
+    outd.mkdir()
+    subprocess.check_call([exe, "--batch", str(outd)] + [os.path.join(golden_io.GOLDEN_DIR, "streams", n) for n in names], timeout=600)
+    for n in names:
+        lhp, b2 = str(outd / (n + ".lhp")), str(tmp_path / (n + ".back"))
+        subprocess.check_call([exe, lhp, b2], timeout=300)
+        orig = open(os.path.join(golden_io.GOLDEN_DIR, "streams", n), "rb").read()
+        assert open(b2, "rb").read() == orig, n
+        assert os.path.getsize(lhp) <= len(orig) + 24
+    assert os.path.getsize(str(outd / "SVA_BA2_D.264.lhp")) < os.path.getsize(os.path.join(golden_io.GOLDEN_DIR, "streams", "SVA_BA2_D.264")) + 300
+    assert os.path.getsize(str(outd / "tibby8x8cavlc.264.lhp")) < 140000
