@@ -2,6 +2,7 @@
 // (intra mode and motion vector prediction), 9.2 (CAVLC).  Frame (progressive) pictures, I and P slices, one slice
 // group -- the subset the reference decoder itself supports.
 #include "h264_parser.h"
+#include <mutex>
 #include "pip_symbols.h"
 #include "h264_cabac_tables.h"
 #include <string.h>
@@ -12,28 +13,48 @@
 namespace lh264host {
 
 namespace {
-struct ZeroCache {                  // per thread: up to kKeep released blocks, matched by exact size
-  enum { kKeep = 512 };
+// released coefficient planes, matched by exact size.  Per thread first (no lock); what a thread cannot keep, and what it
+// leaves behind when it ends, goes to a shared pool so that batches parsed by short-lived worker threads still recycle.
+struct SharedZeroPool {
+  std::mutex m;
+  std::map<size_t, std::vector<void*>> by_size;
+  size_t bytes = 0;
+  ~SharedZeroPool() { for (auto& kv : by_size) for (void* p : kv.second) free (p); }
+  void* get (size_t b) {
+    std::lock_guard<std::mutex> g (m);
+    auto it = by_size.find (b);
+    if (it == by_size.end() || it->second.empty()) return nullptr;
+    void* p = it->second.back(); it->second.pop_back(); bytes -= b;
+    return p;
+  }
+  bool put (void* p, size_t b) {
+    std::lock_guard<std::mutex> g (m);
+    if (bytes + b > ((size_t)4 << 30)) return false;
+    by_size[b].push_back (p); bytes += b;
+    return true;
+  }
+};
+SharedZeroPool& shared_pool() { static SharedZeroPool p; return p; }
+struct ZeroCache {
+  enum { kKeep = 256 };
   struct E { void* p; size_t bytes; } e[kKeep];
   int n = 0;
-  ~ZeroCache() { for (int i = 0; i < n; i++) free (e[i].p); }
+  ~ZeroCache() { for (int i = 0; i < n; i++) if (!shared_pool().put (e[i].p, e[i].bytes)) free (e[i].p); }
 };
 thread_local ZeroCache g_zero_cache;
 }
 void* zerobuf_get (size_t bytes) {
   ZeroCache& c = g_zero_cache;
-  for (int i = c.n - 1; i >= 0; i--) if (c.e[i].bytes == bytes) {
-      void* p = c.e[i].p;
-      c.e[i] = c.e[--c.n];
-      memset (p, 0, bytes);
-      return p;
-    }
+  void* p = nullptr;
+  for (int i = c.n - 1; i >= 0; i--) if (c.e[i].bytes == bytes) { p = c.e[i].p; c.e[i] = c.e[--c.n]; break; }
+  if (!p && bytes >= 4096) p = shared_pool().get (bytes);
+  if (p) { memset (p, 0, bytes); return p; }
   return calloc (1, bytes);
 }
 void zerobuf_put (void* p, size_t bytes) {
   ZeroCache& c = g_zero_cache;
   if (c.n < ZeroCache::kKeep && bytes <= (size_t)8 << 20) { c.e[c.n].p = p; c.e[c.n].bytes = bytes; c.n++; }
-  else free (p);
+  else if (bytes < 4096 || !shared_pool().put (p, bytes)) free (p);
 }
 
 bool BitReader::more_rbsp_data() const {
@@ -138,7 +159,8 @@ struct Parser::Impl {
   int persist_w = 0, persist_h = 0;
   int slice_cached_qp = 0, slice_run_before = 0;
   Symbolizer symbolizer;
-  int last_hdr_bits = -1; bool last_cabac = false;       // the slice NAL just handled: header length in bits, entropy mode
+  int last_hdr_bits = -1; bool last_cabac = false;
+  int16_t no_coef[384];                                  // where the dequantised coefficients go when nobody wants them       // the slice NAL just handled: header length in bits, entropy mode
 
   explicit Impl (Parser* s) : self (s) {}
 
@@ -437,7 +459,8 @@ struct Parser::Impl {
     cur->crop_w = S.mb_w * 16 - 2 * (S.crop_l + S.crop_r); cur->crop_h = S.mb_h * 16 - 2 * (S.crop_t + S.crop_b);
     const size_t n = (size_t)S.mb_w * S.mb_h;
     cur->mbs.assign (n, lh264_mb_t()); memset (cur->mbs.data(), 0, n * sizeof (lh264_mb_t));
-    cur->coeffs.assign_zero ((size_t)n * 384); cur->levels.assign_zero ((size_t)n * 384); cur->covered.assign (n, 0);
+    if (self->want_coeffs_) cur->coeffs.assign_zero ((size_t)n * 384);
+    cur->levels.assign_zero ((size_t)n * 384); cur->covered.assign (n, 0);
     cur->syn.assign (n, MbSyn()); memset (cur->syn.data(), 0, n * sizeof (MbSyn));
     if (persist_w != S.mb_w || persist_h != S.mb_h) {       // the decoder re-allocates (zeroed) on a resolution change
       persist_w = S.mb_w; persist_h = S.mb_h;
@@ -715,7 +738,7 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
   cur->covered[k] = 1;
   for (int i = 0; i < 16; i++) { s.ipm[i] = 2; s.mv[i][0] = s.mv[i][1] = 0; }
   for (int i = 0; i < 4; i++) { s.ref[i] = -1; m.ref_idx[i] = -1; }
-  int16_t* coef = &cur->coeffs[(size_t)k * 384];
+  int16_t* coef = self->want_coeffs_ ? &cur->coeffs[(size_t)k * 384] : no_coef;
   int16_t* lev = &cur->levels[(size_t)k * 384];
   const bool use_sl = S.scaling_matrix_present || P.scaling_matrix_present;
   auto set_qp = [&] (int qp) {
@@ -1061,7 +1084,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
   for (int i = 0; i < 16; i++) { s.ipm[i] = 2; s.mv[i][0] = s.mv[i][1] = 0; s.mvd[i][0] = s.mvd[i][1] = 0; }
   for (int i = 0; i < 4; i++) { s.ref[i] = -1; m.ref_idx[i] = -1; }
   s.skip = 0; s.pcm = 0; s.t8 = 0; s.cbp = 0; s.chroma_pred = 0; s.cbf = 0;
-  int16_t* coef = &cur->coeffs[(size_t)k * 384];
+  int16_t* coef = self->want_coeffs_ ? &cur->coeffs[(size_t)k * 384] : no_coef;
   int16_t* lev = &cur->levels[(size_t)k * 384];
   const bool use_sl = S.scaling_matrix_present || P.scaling_matrix_present;
   const int kA = ((k % w) && mb_avail (k - 1, sid)) ? k - 1 : -1, kB = (k >= w && mb_avail (k - w, sid)) ? k - w : -1;

@@ -207,6 +207,9 @@ class Parser {
   // keep == false: a completed picture is counted and released at once (its buffers go back to the per-thread cache), as a
   // pipeline does after handing the records to the device; frames() then stays empty
   void set_keep_frames (bool keep) { keep_frames_ = keep; }
+  // want == false: FrameOut::coeffs (the dequantised coefficients, only the reconstruct kernel reads them) stays empty -
+  // the compress direction needs the raw levels only, and the planes are what the front end spends its memory bandwidth on
+  void set_want_coeffs (bool want) { want_coeffs_ = want; }
   long pictures_done() const { return pictures_done_; }
 
  private:
@@ -215,7 +218,7 @@ class Parser {
   std::vector<std::unique_ptr<FrameOut>> frames_;
   std::string err_;
   int n_unsupported_ = 0;
-  bool keep_frames_ = true; long pictures_done_ = 0;
+  bool keep_frames_ = true, want_coeffs_ = true; long pictures_done_ = 0;
   MainStreamWriter main_;
   friend struct Impl;
 };

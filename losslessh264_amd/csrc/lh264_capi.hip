@@ -37,18 +37,6 @@ static int fail (int code, const char* what, hipError_t e = hipSuccess) {
 }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail (LH264_E_HIP, #call, e_); } while (0)
 
-template <typename F> static void run_parallel (int n, int threads, F&& fn) {
-  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
-  if (threads < 1) threads = 1;
-  if (threads > n) threads = n;
-  std::atomic<int> next (0);
-  auto worker = [&] () { for (;;) { const int i = next.fetch_add (1); if (i >= n) break; fn (i); } };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < threads; t++) pool.emplace_back (worker);
-  worker();
-  for (auto& t : pool) t.join();
-}
-
 extern "C" {
 
 int lh264_abi_version (void) { return LH264_ABI_VERSION; }

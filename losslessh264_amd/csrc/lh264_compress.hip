@@ -7,6 +7,10 @@
 #include <string.h>
 #include <algorithm>
 #include <memory>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
+#include <thread>
 #include <string>
 #include <vector>
 #include "../../include/lh264.h"
@@ -24,16 +28,42 @@ struct lh264_compressed {
 
 namespace {
 
-struct DevBuf {
-  void* p = nullptr;
+static bool trace_on() { static const bool t = getenv ("LH264_TRACE_COMPRESS") != nullptr; return t; }
+static double now_s() { return std::chrono::duration<double> (std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct DevBuf {                       // device memory, grown when a group needs more, reused otherwise
+  void* p = nullptr; size_t cap = 0;
   ~DevBuf() { if (p) hipFree (p); }
   bool alloc (size_t bytes, bool zero) {
-    if (p) { hipFree (p); p = nullptr; }
-    if (hipMalloc (&p, bytes ? bytes : 16) != hipSuccess) { p = nullptr; return false; }
-    if (zero && hipMemset (p, 0, bytes ? bytes : 16) != hipSuccess) return false;
+    if (bytes < 16) bytes = 16;
+    if (bytes > cap) {
+      if (p) { hipFree (p); p = nullptr; cap = 0; }
+      const size_t want = bytes + bytes / 8;
+      if (hipMalloc (&p, want) != hipSuccess) { p = nullptr; return false; }
+      cap = want;
+    }
+    if (zero && hipMemsetAsync (p, 0, bytes, nullptr) != hipSuccess) return false;
     return true;
   }
   template <typename T> T* as() const { return (T*)p; }
+};
+struct PinBuf {                       // page-locked staging memory (the upload runs at PCIe speed and asynchronously)
+  void* p = nullptr; size_t cap = 0;
+  ~PinBuf() { if (p) hipHostFree (p); }
+  bool alloc (size_t bytes) {
+    if (bytes < 16) bytes = 16;
+    if (bytes <= cap) return true;
+    if (p) { hipHostFree (p); p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 8;
+    if (hipHostMalloc (&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+    cap = want;
+    return true;
+  }
+  template <typename T> T* as() const { return (T*)p; }
+};
+struct Arena {
+  DevBuf d_mbs, d_lev, d_sl, d_nnz, d_syms, d_nsyms, d_cj, d_first, d_syn, d_off, d_kj, d_st, d_keys, d_cells, d_out, d_len;
+  PinBuf h_mbs, h_lev, h_sl, h_syn, h_off;
 };
 
 // which earlier picture the reference's FreqImage holds as PAST (decoded_macroblock.h:119-123): two buffers, flipped when
@@ -53,51 +83,58 @@ void fail_all (lh264_compressed_t** out, const std::vector<int>& idx, int code, 
 }
 
 // one sub-batch: streams idx[0..] of `parsers`, all parsed without error
-void compress_group (std::vector<lh264host::Parser*>& parsers, const std::vector<int>& idx, const size_t* len, lh264_compressed_t** out) {
+void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& parsers, const std::vector<int>& idx, const size_t* len,
+                     lh264_compressed_t** out, int threads) {
   using lh264host::FrameOut;
-  size_t n_mbs = 0, n_slices = 0, n_jobs = 0, n_syn = 0, n_off = 0;
+  const int n_chains = (int)idx.size();
+  // where every stream's records go
+  std::vector<size_t> mb0 (n_chains + 1, 0), sl0 (n_chains + 1, 0), sy0 (n_chains + 1, 0), of0 (n_chains + 1, 0), jb0 (n_chains + 1, 0);
   int max_mbs = 1;
-  for (int i : idx) for (auto& f : parsers[i]->frames()) {
+  for (int c = 0; c < n_chains; c++) {
+    size_t m = 0, sl = 0, sy = 0, of = 0, jb = 0;
+    for (auto& f : parsers[idx[c]]->frames()) {
       const size_t n = (size_t)f->mb_w * f->mb_h;
-      n_mbs += n; n_slices += f->slices.size(); n_jobs++; n_syn += f->syn_syms.size(); n_off += n + 1;
+      m += n; sl += f->slices.size(); sy += f->syn_syms.size(); of += n + 1; jb++;
       max_mbs = std::max (max_mbs, (int)n);
     }
-  const int n_chains = (int)idx.size();
+    mb0[c + 1] = mb0[c] + m; sl0[c + 1] = sl0[c] + sl; sy0[c + 1] = sy0[c] + sy; of0[c + 1] = of0[c] + of; jb0[c + 1] = jb0[c] + jb;
+  }
+  const size_t n_mbs = mb0[n_chains], n_slices = sl0[n_chains], n_syn = sy0[n_chains], n_off = of0[n_chains], n_jobs = jb0[n_chains];
   if (n_jobs == 0) return;
-  // ---- host staging ------------------------------------------------------------------------------------------------------
-  std::vector<lh264_mb_t> h_mbs (n_mbs);
-  std::vector<int16_t> h_lev (n_mbs * 384);
-  std::vector<lh264_slice_t> h_sl (n_slices);
-  std::vector<lh264_ctx_sym_t> h_syn (std::max<size_t> (n_syn, 1));
-  std::vector<uint32_t> h_off (n_off);
   std::vector<lh264_ctx_job_t> h_cj (n_jobs);
   std::vector<lh264_code_job_t> h_kj (n_jobs);
   std::vector<int32_t> h_first (n_chains + 1);
   std::vector<lh264_code_stream_t> h_st (n_chains);
   std::vector<uint32_t> hash_cap (n_chains), out_cap (n_chains);
-  size_t keys_total = 0, out_total = 0;
+  std::vector<size_t> key0 (n_chains + 1, 0), out0 (n_chains + 1, 0);
   for (int c = 0; c < n_chains; c++) {
-    size_t mbs = 0;
-    for (auto& f : parsers[idx[c]]->frames()) mbs += (size_t)f->mb_w * f->mb_h;
+    const size_t mbs = mb0[c + 1] - mb0[c];
     uint32_t hc = 1u << 16;
     while (hc < mbs * 8 && hc < (1u << 22)) hc <<= 1;       // cells touched grow far slower than macroblocks; status 1 reports a full table
-    hash_cap[c] = hc; keys_total += hc;
+    hash_cap[c] = hc; key0[c + 1] = key0[c] + hc;
     out_cap[c] = (uint32_t)std::max<size_t> (1u << 16, 2 * len[idx[c]] + 4096);
-    out_total += (size_t)LH264_N_TAG_SLOTS * out_cap[c];
+    out0[c + 1] = out0[c] + (size_t)LH264_N_TAG_SLOTS * out_cap[c];
   }
-  DevBuf d_mbs, d_lev, d_sl, d_nnz, d_syms, d_nsyms, d_cj, d_first, d_syn, d_off, d_kj, d_st, d_keys, d_cells, d_out, d_len;
-  const bool ok = d_mbs.alloc (n_mbs * sizeof (lh264_mb_t), false) && d_lev.alloc (n_mbs * 768, false) && d_sl.alloc (n_slices * sizeof (lh264_slice_t), false) &&
-                  d_nnz.alloc (n_mbs * 24, true) && d_syms.alloc (n_mbs * LH264_CTX_MAX_SYMS * sizeof (lh264_ctx_sym_t), false) && d_nsyms.alloc (n_mbs * 2, true) &&
-                  d_cj.alloc (n_jobs * sizeof (lh264_ctx_job_t), false) && d_first.alloc ((n_chains + 1) * 4, false) && d_syn.alloc (h_syn.size() * sizeof (lh264_ctx_sym_t), false) &&
-                  d_off.alloc (n_off * 4, false) && d_kj.alloc (n_jobs * sizeof (lh264_code_job_t), false) && d_st.alloc (n_chains * sizeof (lh264_code_stream_t), false) &&
-                  d_keys.alloc (keys_total * 4, true) && d_cells.alloc (keys_total * 64, true) && d_out.alloc (out_total, false) &&
-                  d_len.alloc ((size_t)n_chains * (LH264_N_TAG_SLOTS + 1) * 4, true);
+  const size_t keys_total = key0[n_chains], out_total = out0[n_chains];
+  const double t_a = now_s();
+  const bool ok = A.d_mbs.alloc (n_mbs * sizeof (lh264_mb_t), false) && A.d_lev.alloc (n_mbs * 768, false) && A.d_sl.alloc (n_slices * sizeof (lh264_slice_t), false) &&
+                  A.d_nnz.alloc (n_mbs * 24, true) && A.d_syms.alloc (n_mbs * LH264_CTX_MAX_SYMS * sizeof (lh264_ctx_sym_t), false) && A.d_nsyms.alloc (n_mbs * 2, true) &&
+                  A.d_cj.alloc (n_jobs * sizeof (lh264_ctx_job_t), false) && A.d_first.alloc ((n_chains + 1) * 4, false) && A.d_syn.alloc (n_syn * sizeof (lh264_ctx_sym_t), false) &&
+                  A.d_off.alloc (n_off * 4, false) && A.d_kj.alloc (n_jobs * sizeof (lh264_code_job_t), false) && A.d_st.alloc (n_chains * sizeof (lh264_code_stream_t), false) &&
+                  A.d_keys.alloc (keys_total * 4, true) && A.d_cells.alloc (keys_total * 64, true) && A.d_out.alloc (out_total, false) &&
+                  A.d_len.alloc ((size_t)n_chains * (LH264_N_TAG_SLOTS + 1) * 4, true) &&
+                  A.h_mbs.alloc (n_mbs * sizeof (lh264_mb_t)) && A.h_lev.alloc (n_mbs * 768) && A.h_sl.alloc (n_slices * sizeof (lh264_slice_t)) &&
+                  A.h_syn.alloc (n_syn * sizeof (lh264_ctx_sym_t)) && A.h_off.alloc (n_off * 4);
   if (!ok) { fail_all (out, idx, LH264_E_HIP, "device allocation failed"); return; }
-  size_t mo = 0, so = 0, yo = 0, oo = 0, j = 0, ko = 0, uo = 0;
-  std::vector<int> past;
-  for (int c = 0; c < n_chains; c++) {
+  const double t_b = now_s();
+  lh264_mb_t* h_mbs = A.h_mbs.as<lh264_mb_t>(); int16_t* h_lev = A.h_lev.as<int16_t>(); lh264_slice_t* h_sl = A.h_sl.as<lh264_slice_t>();
+  lh264_ctx_sym_t* h_syn = A.h_syn.as<lh264_ctx_sym_t>(); uint32_t* h_off = A.h_off.as<uint32_t>();
+  // staging: every stream copies its pictures to its place (host threads), and writes its job records
+  run_parallel (n_chains, threads, [&] (int c) {
     auto& fr = parsers[idx[c]]->frames();
+    size_t mo = mb0[c], so = sl0[c], yo = sy0[c], oo = of0[c], j = jb0[c];
     h_first[c] = (int32_t)j;
+    std::vector<int> past;
     past_policy (fr, past);
     std::vector<size_t> mb_at (fr.size());
     for (size_t i = 0; i < fr.size(); i++) {
@@ -110,46 +147,50 @@ void compress_group (std::vector<lh264host::Parser*>& parsers, const std::vector
       if (!f.syn_syms.empty()) memcpy (&h_syn[yo], f.syn_syms.data(), f.syn_syms.size() * sizeof (lh264_ctx_sym_t));
       memcpy (&h_off[oo], f.syn_off.data(), (n + 1) * 4);
       lh264_ctx_job_t& cj = h_cj[j];
-      cj.mbs_dev = d_mbs.as<lh264_mb_t>() + mo; cj.levels_dev = d_lev.as<int16_t>() + mo * 384; cj.slices_dev = d_sl.as<lh264_slice_t>() + so;
-      cj.nnz_cur_dev = d_nnz.as<uint8_t>() + mo * 24;
-      cj.nnz_past_dev = past[i] < 0 ? nullptr : d_nnz.as<uint8_t>() + mb_at[past[i]] * 24;
-      cj.syms_dev = d_syms.as<lh264_ctx_sym_t>() + mo * LH264_CTX_MAX_SYMS; cj.n_syms_dev = d_nsyms.as<uint16_t>() + mo;
+      cj.mbs_dev = A.d_mbs.as<lh264_mb_t>() + mo; cj.levels_dev = A.d_lev.as<int16_t>() + mo * 384; cj.slices_dev = A.d_sl.as<lh264_slice_t>() + so;
+      cj.nnz_cur_dev = A.d_nnz.as<uint8_t>() + mo * 24;
+      cj.nnz_past_dev = past[i] < 0 ? nullptr : A.d_nnz.as<uint8_t>() + mb_at[past[i]] * 24;
+      cj.syms_dev = A.d_syms.as<lh264_ctx_sym_t>() + mo * LH264_CTX_MAX_SYMS; cj.n_syms_dev = A.d_nsyms.as<uint16_t>() + mo;
       cj.mb_w = f.mb_w; cj.mb_h = f.mb_h;
       lh264_code_job_t& kj = h_kj[j];
-      kj.syn_syms_dev = d_syn.as<lh264_ctx_sym_t>() + yo; kj.syn_off_dev = d_off.as<uint32_t>() + oo;
+      kj.syn_syms_dev = A.d_syn.as<lh264_ctx_sym_t>() + yo; kj.syn_off_dev = A.d_off.as<uint32_t>() + oo;
       kj.ctx_syms_dev = cj.syms_dev; kj.ctx_n_syms_dev = cj.n_syms_dev; kj.n_mbs = (int32_t)n; kj.reserved = 0;
       mo += n; so += f.slices.size(); yo += f.syn_syms.size(); oo += n + 1; j++;
     }
     lh264_code_stream_t& st = h_st[c];
-    st.hash_keys_dev = d_keys.as<uint32_t>() + ko; st.hash_cells_dev = d_cells.as<uint32_t>() + ko * 16;
-    st.out_dev = d_out.as<uint8_t>() + uo; st.out_len_dev = d_len.as<uint32_t>() + (size_t)c * (LH264_N_TAG_SLOTS + 1);
+    st.hash_keys_dev = A.d_keys.as<uint32_t>() + key0[c]; st.hash_cells_dev = A.d_cells.as<uint32_t>() + key0[c] * 16;
+    st.out_dev = A.d_out.as<uint8_t>() + out0[c]; st.out_len_dev = A.d_len.as<uint32_t>() + (size_t)c * (LH264_N_TAG_SLOTS + 1);
     st.hash_cap = hash_cap[c]; st.out_cap = out_cap[c];
-    ko += hash_cap[c]; uo += (size_t)LH264_N_TAG_SLOTS * out_cap[c];
-  }
-  h_first[n_chains] = (int32_t)j;
-  auto up = [] (DevBuf& d, const void* s, size_t bytes) { return bytes == 0 || hipMemcpy (d.p, s, bytes, hipMemcpyHostToDevice) == hipSuccess; };
-  if (!(up (d_mbs, h_mbs.data(), n_mbs * sizeof (lh264_mb_t)) && up (d_lev, h_lev.data(), n_mbs * 768) && up (d_sl, h_sl.data(), n_slices * sizeof (lh264_slice_t)) &&
-        up (d_syn, h_syn.data(), n_syn * sizeof (lh264_ctx_sym_t)) && up (d_off, h_off.data(), n_off * 4) && up (d_cj, h_cj.data(), n_jobs * sizeof (lh264_ctx_job_t)) &&
-        up (d_kj, h_kj.data(), n_jobs * sizeof (lh264_code_job_t)) && up (d_first, h_first.data(), (n_chains + 1) * 4) && up (d_st, h_st.data(), n_chains * sizeof (lh264_code_stream_t)))) {
+  });
+  h_first[n_chains] = (int32_t)n_jobs;
+  const double t_c = now_s();
+  auto up = [] (DevBuf& d, const void* s, size_t bytes) { return bytes == 0 || hipMemcpyAsync (d.p, s, bytes, hipMemcpyHostToDevice, nullptr) == hipSuccess; };
+  if (!(up (A.d_mbs, h_mbs, n_mbs * sizeof (lh264_mb_t)) && up (A.d_lev, h_lev, n_mbs * 768) && up (A.d_sl, h_sl, n_slices * sizeof (lh264_slice_t)) &&
+        up (A.d_syn, h_syn, n_syn * sizeof (lh264_ctx_sym_t)) && up (A.d_off, h_off, n_off * 4) && up (A.d_cj, h_cj.data(), n_jobs * sizeof (lh264_ctx_job_t)) &&
+        up (A.d_kj, h_kj.data(), n_jobs * sizeof (lh264_code_job_t)) && up (A.d_first, h_first.data(), (n_chains + 1) * 4) && up (A.d_st, h_st.data(), n_chains * sizeof (lh264_code_stream_t)))) {
     fail_all (out, idx, LH264_E_HIP, "upload failed"); return;
   }
-  int rc = lh264_ctx_index_chains (d_cj.as<lh264_ctx_job_t>(), d_first.as<int32_t>(), n_chains, (int)n_jobs, max_mbs, nullptr);
-  if (rc == LH264_OK) rc = lh264_code_chains (d_kj.as<lh264_code_job_t>(), d_first.as<int32_t>(), d_st.as<lh264_code_stream_t>(), n_chains, nullptr);
+  if (trace_on()) hipDeviceSynchronize();
+  const double t_d = now_s();
+  int rc = lh264_ctx_index_chains (A.d_cj.as<lh264_ctx_job_t>(), A.d_first.as<int32_t>(), n_chains, (int)n_jobs, max_mbs, nullptr);
+  if (rc == LH264_OK) rc = lh264_code_chains (A.d_kj.as<lh264_code_job_t>(), A.d_first.as<int32_t>(), A.d_st.as<lh264_code_stream_t>(), n_chains, nullptr);
   if (rc != LH264_OK || hipDeviceSynchronize() != hipSuccess) { fail_all (out, idx, rc != LH264_OK ? rc : LH264_E_HIP, "kernel launch failed"); return; }
+  const double t_e = now_s();
   std::vector<uint32_t> lens ((size_t)n_chains * (LH264_N_TAG_SLOTS + 1));
-  if (hipMemcpy (lens.data(), d_len.p, lens.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail_all (out, idx, LH264_E_HIP, "download failed"); return; }
-  uo = 0;
+  if (hipMemcpy (lens.data(), A.d_len.p, lens.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail_all (out, idx, LH264_E_HIP, "download failed"); return; }
   for (int c = 0; c < n_chains; c++) {
     lh264_compressed_t& r = *out[idx[c]];
     const uint32_t* L = &lens[(size_t)c * (LH264_N_TAG_SLOTS + 1)];
-    if (L[LH264_N_TAG_SLOTS] != 0) { r.status = LH264_E_HIP; r.error = "device coder status " + std::to_string (L[LH264_N_TAG_SLOTS]) + " (1: prior table full, 4: output overflow)"; }
-    else for (int slot = 0; slot < 35; slot++) if (L[slot]) {
-          const int tag = slot == 34 ? 69 : slot;
-          r.tag[tag].resize (L[slot]); r.has_tag[tag] = true;
-          if (hipMemcpy (r.tag[tag].data(), d_out.as<uint8_t>() + uo + (size_t)slot * out_cap[c], L[slot], hipMemcpyDeviceToHost) != hipSuccess) { r.status = LH264_E_HIP; r.error = "download failed"; }
-        }
-    uo += (size_t)LH264_N_TAG_SLOTS * out_cap[c];
+    if (L[LH264_N_TAG_SLOTS] != 0) { r.status = LH264_E_HIP; r.error = "device coder status " + std::to_string (L[LH264_N_TAG_SLOTS]) + " (1: prior table full, 4: output overflow)"; continue; }
+    for (int slot = 0; slot < 35; slot++) if (L[slot]) {
+        const int tag = slot == 34 ? 69 : slot;
+        r.tag[tag].resize (L[slot]); r.has_tag[tag] = true;
+        if (hipMemcpyAsync (r.tag[tag].data(), A.d_out.as<uint8_t>() + out0[c] + (size_t)slot * out_cap[c], L[slot], hipMemcpyDeviceToHost, nullptr) != hipSuccess) { r.status = LH264_E_HIP; r.error = "download failed"; }
+      }
   }
+  if (hipDeviceSynchronize() != hipSuccess) fail_all (out, idx, LH264_E_HIP, "download failed");
+  if (trace_on()) fprintf (stderr, "[lh264 compress] group of %d streams, %zu MBs: alloc+clear %.3f s, staging %.3f, upload %.3f, kernels %.3f, download %.3f\n", n_chains, n_mbs,
+                           t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, now_s() - t_e);
 }
 
 }  // namespace
@@ -160,32 +201,54 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
   if (!data || !len || !out || n < 0) return LH264_E_ARG;
   for (int i = 0; i < n; i++) out[i] = new lh264_compressed();
   if (lh264_device_count() <= 0) { for (int i = 0; i < n; i++) { out[i]->status = LH264_E_NODEVICE; out[i]->error = "no HIP device visible"; } return LH264_E_NODEVICE; }
-  std::vector<lh264_parser_t*> ph (n, nullptr);
-  const int rc = lh264_parse_batch (data, len, n, threads, ph.data());
-  if (rc != LH264_OK) { for (auto p : ph) if (p) lh264_parser_destroy (p); return rc; }
-  std::vector<lh264host::Parser*> parsers (n);
-  for (int i = 0; i < n; i++) parsers[i] = lh264_parser_impl (ph[i]);
-  // sub-batches bounded by macroblock count (the symbol buffer takes 3.4 KB per macroblock)
-  const size_t kBudget = 1500000;
+  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+  if (threads < 1) threads = 1;
+  int device = 0;
+  hipGetDevice (&device);
+  // Streams are parsed in waves on the host threads; parsed streams collect into a group until the group is worth a launch
+  // (bounded by macroblock count: the symbol buffer takes 3.4 KB per macroblock); the group's staging, upload, kernels and
+  // download run on their own host thread while the next wave is being parsed.
+  const size_t kBudget = 2600000;
+  const int kWave = std::max (8, 4 * threads);
+  Arena arena;
+  std::vector<std::unique_ptr<lh264host::Parser>> parsers (n);
+  std::thread device_thread;
+  std::vector<int> running;                       // the group the device thread works on (its parsers are released when it is done)
+  auto launch = [&] (std::vector<int>& group) {
+    if (device_thread.joinable()) { device_thread.join(); for (int i : running) parsers[i].reset(); }
+    running.swap (group); group.clear();
+    if (running.empty()) return;
+    device_thread = std::thread ([&, device] () { hipSetDevice (device); compress_group (arena, parsers, running, len, out, std::max (1, threads / 2)); });
+  };
   std::vector<int> group;
   size_t in_group = 0;
-  auto flush = [&] () { if (!group.empty()) compress_group (parsers, group, len, out); group.clear(); in_group = 0; };
-  for (int i = 0; i < n; i++) {
-    lh264_compressed_t& r = *out[i];
-    lh264host::Parser& P = *parsers[i];
-    r.main_stream = P.main_stream();
-    r.pictures = (int)P.frames().size();
-    if (!P.error().empty()) { r.status = LH264_E_UNSUPPORTED; r.error = P.error(); continue; }
-    size_t mbs = 0;
-    bool symbols = true;
-    for (auto& f : P.frames()) { mbs += (size_t)f->mb_w * f->mb_h; symbols = symbols && f->syn_off.size() == (size_t)f->mb_w * f->mb_h + 1 && (f->syn_off.back() == f->syn_syms.size()); }
-    if (!symbols) { r.status = LH264_E_UNSUPPORTED; r.error = "a picture with an incomplete slice"; continue; }
-    if (mbs == 0) continue;
-    if (in_group && in_group + mbs > kBudget) flush();
-    group.push_back (i); in_group += mbs;
+  for (int w0 = 0; w0 < n; w0 += kWave) {
+    const int w1 = std::min (n, w0 + kWave);
+    const double t_p = now_s();
+    run_parallel (w1 - w0, threads, [&] (int k) {
+      const int i = w0 + k;
+      parsers[i].reset (new lh264host::Parser());
+      parsers[i]->set_want_coeffs (false);
+      if (data[i] || !len[i]) parsers[i]->feed_file (data[i], len[i]);
+    });
+    if (trace_on()) fprintf (stderr, "[lh264 compress] wave of %d streams parsed in %.3f s\n", w1 - w0, now_s() - t_p);
+    for (int i = w0; i < w1; i++) {
+      lh264_compressed_t& r = *out[i];
+      lh264host::Parser& P = *parsers[i];
+      r.main_stream = P.main_stream();
+      r.pictures = (int)P.frames().size();
+      size_t mbs = 0;
+      bool symbols = true;
+      for (auto& f : P.frames()) { mbs += (size_t)f->mb_w * f->mb_h; symbols = symbols && f->syn_off.size() == (size_t)f->mb_w * f->mb_h + 1 && (f->syn_off.back() == f->syn_syms.size()); }
+      if (!P.error().empty()) { r.status = LH264_E_UNSUPPORTED; r.error = P.error(); }
+      else if (!symbols) { r.status = LH264_E_UNSUPPORTED; r.error = "a picture with an incomplete slice"; }
+      if (r.status != LH264_OK || mbs == 0) { parsers[i].reset(); continue; }
+      if (in_group && in_group + mbs > kBudget) { launch (group); in_group = 0; }
+      group.push_back (i); in_group += mbs;
+    }
   }
-  flush();
-  for (auto p : ph) lh264_parser_destroy (p);
+  launch (group);
+  if (device_thread.joinable()) device_thread.join();
   return LH264_OK;
 }
 int lh264_compressed_status (const lh264_compressed_t* c) { return c ? c->status : LH264_E_ARG; }

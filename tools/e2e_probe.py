@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""end-to-end wall time of lh264_compress_batch (parse on host threads + staging + upload + kernels + download) on N copies of the
+bench stream, and of lh264_pip_restore_batch on the result"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401  (HIP runtime first)
+import losslessh264_amd as lh
+data = open(os.path.join(ROOT, "tests", "golden", "streams", "BA_MW_D.264"), "rb").read()
+for n in [int(a) for a in sys.argv[1:]] or [64, 512]:
+    lh.compress_batch([data] * 4, 16)
+    t0 = time.perf_counter()
+    res = lh.compress_batch([data] * n, 16)
+    dt = time.perf_counter() - t0
+    assert all(e is None for _, _, e in res) and sum(len(b) for b in res[-1][1].values()) == 52742
+    t1 = time.perf_counter()
+    outs = lh.restore_batch([(m, t) for m, t, _ in res], 16)
+    dr = time.perf_counter() - t1
+    assert all(o == data for o in outs)
+    print("streams=%d  compress_batch %.2f s (%.1f MB/s end to end)   restore_batch %.2f s (%.1f MB/s)" % (n, dt, n * len(data) / dt / 1e6, dr, n * len(data) / dr / 1e6), flush=True)
