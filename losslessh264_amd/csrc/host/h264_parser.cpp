@@ -43,13 +43,13 @@ struct ZeroCache {
 };
 thread_local ZeroCache g_zero_cache;
 }
-void* zerobuf_get (size_t bytes) {
+void* zerobuf_get (size_t bytes, bool zero) {
   ZeroCache& c = g_zero_cache;
   void* p = nullptr;
   for (int i = c.n - 1; i >= 0; i--) if (c.e[i].bytes == bytes) { p = c.e[i].p; c.e[i] = c.e[--c.n]; break; }
   if (!p && bytes >= 4096) p = shared_pool().get (bytes);
-  if (p) { memset (p, 0, bytes); return p; }
-  return calloc (1, bytes);
+  if (p) { if (zero) memset (p, 0, bytes); return p; }
+  return zero ? calloc (1, bytes) : malloc (bytes);
 }
 void zerobuf_put (void* p, size_t bytes) {
   ZeroCache& c = g_zero_cache;
@@ -460,7 +460,7 @@ struct Parser::Impl {
     const size_t n = (size_t)S.mb_w * S.mb_h;
     cur->mbs.assign (n, lh264_mb_t()); memset (cur->mbs.data(), 0, n * sizeof (lh264_mb_t));
     if (self->want_coeffs_) cur->coeffs.assign_zero ((size_t)n * 384);
-    cur->levels.assign_zero ((size_t)n * 384); cur->covered.assign (n, 0);
+    cur->levels.assign_zero ((size_t)n * 384, !self->lazy_levels_); cur->covered.assign (n, 0);
     cur->syn.assign (n, MbSyn()); memset (cur->syn.data(), 0, n * sizeof (MbSyn));
     if (persist_w != S.mb_w || persist_h != S.mb_h) {       // the decoder re-allocates (zeroed) on a resolution change
       persist_w = S.mb_w; persist_h = S.mb_h;
@@ -740,6 +740,7 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
   for (int i = 0; i < 4; i++) { s.ref[i] = -1; m.ref_idx[i] = -1; }
   int16_t* coef = self->want_coeffs_ ? &cur->coeffs[(size_t)k * 384] : no_coef;
   int16_t* lev = &cur->levels[(size_t)k * 384];
+  if (self->lazy_levels_ && !is_skip) memset (lev, 0, 768);
   const bool use_sl = S.scaling_matrix_present || P.scaling_matrix_present;
   auto set_qp = [&] (int qp) {
     m.qp_y = (uint8_t)qp;
@@ -1086,6 +1087,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
   s.skip = 0; s.pcm = 0; s.t8 = 0; s.cbp = 0; s.chroma_pred = 0; s.cbf = 0;
   int16_t* coef = self->want_coeffs_ ? &cur->coeffs[(size_t)k * 384] : no_coef;
   int16_t* lev = &cur->levels[(size_t)k * 384];
+  if (self->lazy_levels_ && !is_skip) memset (lev, 0, 768);
   const bool use_sl = S.scaling_matrix_present || P.scaling_matrix_present;
   const int kA = ((k % w) && mb_avail (k - 1, sid)) ? k - 1 : -1, kB = (k >= w && mb_avail (k - w, sid)) ? k - w : -1;
   auto set_qp = [&] (int qp) {

@@ -120,7 +120,7 @@ struct SliceSyn { int32_t pad_bits, pad_value, transform8x8_pps, flags /* bit 0 
 // they come from).  Released blocks go to a small per-thread cache and are cleared on reuse: handing them back to the C library
 // means fresh page faults for the next picture, and in a process that parses several streams side by side those serialise
 // on the address-space lock (measured: 8 threads 1.8x one thread before, see DESIGN.md host front end).
-void* zerobuf_get (size_t bytes);
+void* zerobuf_get (size_t bytes, bool zero = true);
 void zerobuf_put (void* p, size_t bytes);
 template <typename T> class ZeroBuf {
  public:
@@ -128,7 +128,7 @@ template <typename T> class ZeroBuf {
   ~ZeroBuf() { if (p_) zerobuf_put (p_, n_ * sizeof (T)); }
   ZeroBuf (const ZeroBuf&) = delete;
   ZeroBuf& operator= (const ZeroBuf&) = delete;
-  void assign_zero (size_t n) { if (p_) zerobuf_put (p_, n_ * sizeof (T)); p_ = n ? (T*)zerobuf_get (n * sizeof (T)) : nullptr; n_ = p_ ? n : 0; }
+  void assign_zero (size_t n, bool zero = true) { if (p_) zerobuf_put (p_, n_ * sizeof (T)); p_ = n ? (T*)zerobuf_get (n * sizeof (T), zero) : nullptr; n_ = p_ ? n : 0; }
   T* data() { return p_; }
   const T* data() const { return p_; }
   size_t size() const { return n_; }
@@ -210,6 +210,9 @@ class Parser {
   // want == false: FrameOut::coeffs (the dequantised coefficients, only the reconstruct kernel reads them) stays empty -
   // the compress direction needs the raw levels only, and the planes are what the front end spends its memory bandwidth on
   void set_want_coeffs (bool want) { want_coeffs_ = want; }
+  // lazy == true: FrameOut::levels is cleared macroblock by macroblock as coded macroblocks are parsed; the levels of skipped
+  // or lost macroblocks are then undefined (no kernel reads them: lh264_ctx.hip returns on their type)
+  void set_lazy_levels (bool lazy) { lazy_levels_ = lazy; }
   long pictures_done() const { return pictures_done_; }
 
  private:
@@ -218,7 +221,7 @@ class Parser {
   std::vector<std::unique_ptr<FrameOut>> frames_;
   std::string err_;
   int n_unsupported_ = 0;
-  bool keep_frames_ = true, want_coeffs_ = true; long pictures_done_ = 0;
+  bool keep_frames_ = true, want_coeffs_ = true, lazy_levels_ = false; long pictures_done_ = 0;
   MainStreamWriter main_;
   friend struct Impl;
 };

@@ -229,6 +229,7 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
       const int i = w0 + k;
       parsers[i].reset (new lh264host::Parser());
       parsers[i]->set_want_coeffs (false);
+      parsers[i]->set_lazy_levels (true);
       if (data[i] || !len[i]) parsers[i]->feed_file (data[i], len[i]);
     });
     if (trace_on()) fprintf (stderr, "[lh264 compress] wave of %d streams parsed in %.3f s\n", w1 - w0, now_s() - t_p);
