@@ -180,3 +180,24 @@ def test_cpp_console_application(tmp_path):
         assert os.path.getsize(lhp) <= len(orig) + 24
     assert os.path.getsize(str(outd / "SVA_BA2_D.264.lhp")) < os.path.getsize(os.path.join(golden_io.GOLDEN_DIR, "streams", "SVA_BA2_D.264")) + 300
     assert os.path.getsize(str(outd / "tibby8x8cavlc.264.lhp")) < 140000
+
+
+def test_compress_batch_mixed_good_and_bad_inputs():
+    """one call with good streams, an empty one, garbage, a truncated stream and one the reference cannot decode either: the good ones
+    come out right, the others carry a status and whatever default stream there is, nothing crashes"""
+    import losslessh264_amd as lh
+    rng = np.random.default_rng(9)
+    good = open(os.path.join(golden_io.GOLDEN_DIR, "streams", "SVA_BA2_D.264"), "rb").read()
+    other = open(os.path.join(golden_io.GOLDEN_DIR, "streams", "Static.264"), "rb").read()
+    datas = [good, b"", bytes(rng.integers(0, 256, 3000, dtype=np.uint8)), good[:len(good) // 2], other, good]
+    res = lh.compress_batch(datas, 4)
+    z = np.load(os.path.join(golden_io.GOLDEN_DIR, "cli_SVA_BA2_D.264.npz"))
+    ref = {int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")}
+    for i in (0, 5):
+        assert res[i][2] is None and res[i][0] == z["main"].tobytes() and res[i][1] == ref
+    assert res[4][2] is None and lh.restore(res[4][0], res[4][1]) == other
+    assert res[1][1] == {} and res[2][1] == {}            # nothing to code in an empty / garbage input
+    # the truncated stream: either compressed (then it must round-trip) or reported
+    main, tags, err = res[3]
+    if err is None:
+        assert lh.restore(main, tags) == datas[3]
