@@ -344,6 +344,7 @@ const uint8_t* lh264_compressed_main (const lh264_compressed_t* c, size_t* len);
 const uint8_t* lh264_compressed_tag (const lh264_compressed_t* c, int tag, size_t* len);     /* NULL: the stream does not exist */
 int lh264_compressed_pictures (const lh264_compressed_t* c);
 void lh264_compressed_free (lh264_compressed_t* c);
+void lh264_compress_release (void);       /* frees the device and page-locked buffers lh264_compress_batch keeps between calls */
 
 /* ---- batches of independent streams on the host cores (streams are independent, one thread each) --
  * lh264_parse_batch: n Annex-B files -> n parsers (lh264_parser_feed_file each), `threads` worker threads (0 = one per

@@ -72,6 +72,7 @@ _SIGS.update({
     "lh264_compressed_tag": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "lh264_compressed_pictures": (C.c_int, [C.c_void_p]),
     "lh264_compressed_free": (None, [C.c_void_p]),
+    "lh264_compress_release": (None, []),
     "lh264_pip_pack_bound": (C.c_size_t, [C.c_size_t, C.POINTER(C.c_size_t), C.c_int]),
     "lh264_pip_pack": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lh264_pip_restore_file": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

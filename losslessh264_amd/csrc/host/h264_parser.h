@@ -138,21 +138,36 @@ template <typename T> class ZeroBuf {
   T* p_ = nullptr; size_t n_ = 0;
 };
 
+// std::vector on the same recycled blocks (sizes rounded up to 4 KB so that pictures of one stream reuse each other's blocks):
+// the per-picture arrays of a batch are released by another thread than the one that parses the next streams, and handing
+// them to the C library means trimmed heaps and fresh page faults for every wave of streams
+template <typename T> struct PoolAlloc {
+  typedef T value_type;
+  PoolAlloc() {}
+  template <typename U> PoolAlloc (const PoolAlloc<U>&) {}
+  static size_t round (size_t n) { return ((n * sizeof (T)) + 4095) & ~ (size_t)4095; }
+  T* allocate (size_t n) { return (T*)zerobuf_get (round (n), false); }
+  void deallocate (T* p, size_t n) { zerobuf_put (p, round (n)); }
+  template <typename U> bool operator== (const PoolAlloc<U>&) const { return true; }
+  template <typename U> bool operator!= (const PoolAlloc<U>&) const { return false; }
+};
+template <typename T> using PoolVec = std::vector<T, PoolAlloc<T>>;
+
 // one parsed picture: exactly what lh264_recon_chains / lh264_ctx_index_chains consume
 struct FrameOut {
   int id = 0, mb_w = 0, mb_h = 0, frame_num = 0, crop_w = 0, crop_h = 0, crop_x = 0, crop_y = 0;
   bool idr = false, is_ref = false, complete = false;
-  std::vector<lh264_mb_t> mbs;
+  PoolVec<lh264_mb_t> mbs;
   ZeroBuf<int16_t> coeffs, levels;
   std::vector<lh264_slice_t> slices;
   std::vector<int> ref_ids;             // ids of the pictures this one references (its job's ref slots)
   std::vector<int> dpb_ids;             // ids still marked 'used for reference' once this picture is done (others may be freed)
   int idr_pic_id = 0, nal_ref_idc = 0;
   std::vector<uint8_t> covered;
-  std::vector<MbSyn> syn;               // per macroblock (row a10)
+  PoolVec<MbSyn> syn;                   // per macroblock (row a10)
   std::vector<SliceSyn> slice_syn;      // per slice
-  std::vector<lh264_ctx_sym_t> syn_syms;   // the picture's row-a10 symbols (Symbolizer), macroblock after macroblock
-  std::vector<uint32_t> syn_off;           // mb_w*mb_h + 1 offsets
+  PoolVec<lh264_ctx_sym_t> syn_syms;       // the picture's row-a10 symbols (Symbolizer), macroblock after macroblock
+  PoolVec<uint32_t> syn_off;               // mb_w*mb_h + 1 offsets
 };
 
 // The recompressor's default stream (".pip" itself, stream id 0x7fffffff): the Annex-B input minus its slice data.

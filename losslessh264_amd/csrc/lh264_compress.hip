@@ -7,6 +7,7 @@
 #include <string.h>
 #include <algorithm>
 #include <memory>
+#include <mutex>
 #include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,6 +26,14 @@ struct lh264_compressed {
   bool has_tag[72] = {false};
   int pictures = 0;
 };
+
+// gathers the tagged streams of a group (one workgroup per stream and tag) into one buffer: one download instead of thousands
+struct PackItem { uint64_t src, dst; uint32_t len, pad; };
+__global__ void __launch_bounds__ (256) pack_tags_kernel (const PackItem* __restrict__ items, const uint8_t* __restrict__ out, uint8_t* __restrict__ packed) {
+  const PackItem it = items[blockIdx.x];
+  const uint8_t* s = out + it.src; uint8_t* d = packed + it.dst;
+  for (uint32_t i = threadIdx.x; i < it.len; i += blockDim.x) d[i] = s[i];
+}
 
 namespace {
 
@@ -62,8 +71,8 @@ struct PinBuf {                       // page-locked staging memory (the upload 
   template <typename T> T* as() const { return (T*)p; }
 };
 struct Arena {
-  DevBuf d_mbs, d_lev, d_sl, d_nnz, d_syms, d_nsyms, d_cj, d_first, d_syn, d_off, d_kj, d_st, d_keys, d_cells, d_out, d_len;
-  PinBuf h_mbs, h_lev, h_sl, h_syn, h_off;
+  DevBuf d_mbs, d_lev, d_sl, d_nnz, d_syms, d_nsyms, d_cj, d_first, d_syn, d_off, d_kj, d_st, d_keys, d_cells, d_out, d_len, d_items, d_packed;
+  PinBuf h_mbs, h_lev, h_sl, h_syn, h_off, h_packed;
 };
 
 // which earlier picture the reference's FreqImage holds as PAST (decoded_macroblock.h:119-123): two buffers, flipped when
@@ -178,20 +187,37 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   const double t_e = now_s();
   std::vector<uint32_t> lens ((size_t)n_chains * (LH264_N_TAG_SLOTS + 1));
   if (hipMemcpy (lens.data(), A.d_len.p, lens.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail_all (out, idx, LH264_E_HIP, "download failed"); return; }
+  std::vector<PackItem> items;
+  size_t packed_bytes = 0;
   for (int c = 0; c < n_chains; c++) {
     lh264_compressed_t& r = *out[idx[c]];
     const uint32_t* L = &lens[(size_t)c * (LH264_N_TAG_SLOTS + 1)];
     if (L[LH264_N_TAG_SLOTS] != 0) { r.status = LH264_E_HIP; r.error = "device coder status " + std::to_string (L[LH264_N_TAG_SLOTS]) + " (1: prior table full, 4: output overflow)"; continue; }
     for (int slot = 0; slot < 35; slot++) if (L[slot]) {
-        const int tag = slot == 34 ? 69 : slot;
-        r.tag[tag].resize (L[slot]); r.has_tag[tag] = true;
-        if (hipMemcpyAsync (r.tag[tag].data(), A.d_out.as<uint8_t>() + out0[c] + (size_t)slot * out_cap[c], L[slot], hipMemcpyDeviceToHost, nullptr) != hipSuccess) { r.status = LH264_E_HIP; r.error = "download failed"; }
+        PackItem it; it.src = out0[c] + (size_t)slot * out_cap[c]; it.dst = packed_bytes; it.len = L[slot]; it.pad = (uint32_t)c << 8 | (uint32_t)slot;
+        items.push_back (it);
+        packed_bytes += (L[slot] + 15u) & ~15u;
       }
   }
-  if (hipDeviceSynchronize() != hipSuccess) fail_all (out, idx, LH264_E_HIP, "download failed");
+  if (!items.empty()) {
+    if (!(A.d_items.alloc (items.size() * sizeof (PackItem), false) && A.d_packed.alloc (packed_bytes, false) && A.h_packed.alloc (packed_bytes)) ||
+        hipMemcpyAsync (A.d_items.p, items.data(), items.size() * sizeof (PackItem), hipMemcpyHostToDevice, nullptr) != hipSuccess) { fail_all (out, idx, LH264_E_HIP, "download failed"); return; }
+    hipLaunchKernelGGL (pack_tags_kernel, dim3 ((unsigned)items.size()), dim3 (256), 0, nullptr, A.d_items.as<PackItem>(), A.d_out.as<uint8_t>(), A.d_packed.as<uint8_t>());
+    if (hipMemcpy (A.h_packed.p, A.d_packed.p, packed_bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail_all (out, idx, LH264_E_HIP, "download failed"); return; }
+    const uint8_t* hp = A.h_packed.as<uint8_t>();
+    run_parallel ((int)items.size(), threads, [&] (int k) {
+      const PackItem& it = items[k];
+      lh264_compressed_t& r = *out[idx[it.pad >> 8]];
+      const int slot = (int) (it.pad & 0xff), tag = slot == 34 ? 69 : slot;
+      r.tag[tag].assign (hp + it.dst, hp + it.dst + it.len); r.has_tag[tag] = true;
+    });
+  }
   if (trace_on()) fprintf (stderr, "[lh264 compress] group of %d streams, %zu MBs: alloc+clear %.3f s, staging %.3f, upload %.3f, kernels %.3f, download %.3f\n", n_chains, n_mbs,
                            t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, now_s() - t_e);
 }
+
+std::unique_ptr<Arena> g_arena;
+int g_arena_device = -1;
 
 }  // namespace
 
@@ -208,17 +234,27 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
   // Streams are parsed in waves on the host threads; parsed streams collect into a group until the group is worth a launch
   // (bounded by macroblock count: the symbol buffer takes 3.4 KB per macroblock); the group's staging, upload, kernels and
   // download run on their own host thread while the next wave is being parsed.
-  const size_t kBudget = 2600000;
+  size_t kBudget = 5200000;                       // upper bound; lowered below to a third of the projected work so that groups overlap
   const int kWave = std::max (8, 4 * threads);
-  Arena arena;
+  // device and page-locked buffers live across calls (allocating and releasing ~20 GB costs more than a whole batch):
+  // one arena per process, one compress call at a time; lh264_compress_release() gives the memory back
+  static std::mutex arena_mutex;
+  std::lock_guard<std::mutex> arena_lock (arena_mutex);
+  if (!g_arena || g_arena_device != device) { g_arena.reset (new Arena()); g_arena_device = device; }
+  Arena& arena = *g_arena;
+  const double t_call = now_s();
   std::vector<std::unique_ptr<lh264host::Parser>> parsers (n);
   std::thread device_thread;
   std::vector<int> running;                       // the group the device thread works on (its parsers are released when it is done)
   auto launch = [&] (std::vector<int>& group) {
-    if (device_thread.joinable()) { device_thread.join(); for (int i : running) parsers[i].reset(); }
+    if (device_thread.joinable()) device_thread.join();
     running.swap (group); group.clear();
     if (running.empty()) return;
-    device_thread = std::thread ([&, device] () { hipSetDevice (device); compress_group (arena, parsers, running, len, out, std::max (1, threads / 2)); });
+    device_thread = std::thread ([&, device] () {
+      hipSetDevice (device);
+      compress_group (arena, parsers, running, len, out, std::max (1, threads / 2));
+      for (int i : running) parsers[i].reset();          // the pictures go back to the pool while the next wave is parsed
+    });
   };
   std::vector<int> group;
   size_t in_group = 0;
@@ -233,6 +269,12 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
       if (data[i] || !len[i]) parsers[i]->feed_file (data[i], len[i]);
     });
     if (trace_on()) fprintf (stderr, "[lh264 compress] wave of %d streams parsed in %.3f s\n", w1 - w0, now_s() - t_p);
+    if (w0 == 0) {                                 // project the whole batch from its first wave: macroblocks per input byte
+      size_t mb = 0, by = 0, all = 0;
+      for (int i = w0; i < w1; i++) { by += len[i]; for (auto& f : parsers[i]->frames()) mb += (size_t)f->mb_w * f->mb_h; }
+      for (int i = 0; i < n; i++) all += len[i];
+      if (by) { const double proj = (double)mb / (double)by * (double)all; kBudget = (size_t)std::min (5200000.0, std::max (1300000.0, proj / 3.0)); }
+    }
     for (int i = w0; i < w1; i++) {
       lh264_compressed_t& r = *out[i];
       lh264host::Parser& P = *parsers[i];
@@ -250,8 +292,10 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
   }
   launch (group);
   if (device_thread.joinable()) device_thread.join();
+  if (trace_on()) fprintf (stderr, "[lh264 compress] %d streams: %.3f s\n", n, now_s() - t_call);
   return LH264_OK;
 }
+void lh264_compress_release (void) { g_arena.reset(); }
 int lh264_compressed_status (const lh264_compressed_t* c) { return c ? c->status : LH264_E_ARG; }
 const char* lh264_compressed_error (const lh264_compressed_t* c) { return c ? c->error.c_str() : ""; }
 const uint8_t* lh264_compressed_main (const lh264_compressed_t* c, size_t* len) {
