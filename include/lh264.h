@@ -237,7 +237,7 @@ int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chai
  * coefficient symbols of lh264_ctx_index_chains go) and produces the byte string of every tagged stream exactly as
  * the reference's compressor writes it to <out>.pip.<tag> (ArithmeticCodedOutput / vpx_writer,
  * compression_stream.h:353-487, bitwriter.h:35-105; DynProb :87-115; emitInt / emitUEGkInt :523-591).
- * One workgroup (one wave) per stream; lane t holds the bool-coder state of tag slot t.  The adaptive priors live in
+ * One workgroup (two waves) per stream: one keeps the adaptive state, lane t of the other the bool coder of tag slot t.  The adaptive priors live in
  * a per-stream open-addressing hash table in HBM (a cell = 16 packed DynProbs = 64 bytes), zero-filled by the caller. */
 #define LH264_N_TAG_SLOTS 40
 typedef struct lh264_code_job {

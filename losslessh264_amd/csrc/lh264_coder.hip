@@ -1,18 +1,15 @@
 // lh264_coder.hip - the recompressor's adaptive binary arithmetic coder on the device.
 //
-// One workgroup = one wave64 per stream.  The wave walks the stream's symbols in coding order (host list of syntax
-// symbols per macroblock with the coefficient symbols of lh264_ctx_index_chains spliced in at the marker); the
-// binarisation of a symbol (emitInt / emitUEGkInt / Branch<n> / emitBitsZeroToPow2Inclusive,
-// /root/reference/codec/decoder/core/inc/compression_stream.h:117-166,455-591) is wave-uniform scalar work, the adaptive
-// probabilities of the symbol's prior (DynProb :87-115) are one 64-byte cell of a per-stream open-addressing hash table
-// in HBM held in lanes 0..15 while the symbol is coded, and lane t owns the libvpx bool coder (bitwriter.h:35-105) of tag
-// slot t: a decision for tag t is coded by lane t alone.  The raw-bit probability TEST_PROB (:363,441-448) is shared by
-// all tags and lives in a scalar.  A DynProb is packed into 32 bits (two 10-bit counts and the probability the next
-// decision will use, which is NOT derivable from the counts after a rescale), biased so that zero-filled memory is the
-// initial state.
-//
-// Serial by nature: throughput comes from the number of streams (one wave each) - the dependent chain per symbol is one
-// hash probe + one cell fetch; see DESIGN.md.
+// One workgroup = two wave64 per stream.  The symbol wave walks the stream's symbols in coding order (host list of syntax
+// symbols per macroblock with the coefficient symbols of lh264_ctx_index_chains spliced in at the marker), 64 at a time:
+// every lane binarises its own symbol (emitInt / emitUEGkInt / Branch<n> / emitBitsZeroToPow2Inclusive,
+// /root/reference/codec/decoder/core/inc/compression_stream.h:117-166,455-591) and fetches its prior's cell - the adaptive
+// probabilities (DynProb :87-115), one 64-byte cell of a per-stream open-addressing hash table in HBM - into an LDS row; the
+// rows are advanced by their users in parallel, every decision taking the probability it is coded with; the decisions are
+// sorted by tag and handed to the coding wave, whose lane t owns the libvpx bool coder (bitwriter.h:35-105) of tag slot t.
+// The raw-bit probability TEST_PROB (:363,441-448) is shared by all tags and lives in a scalar of the symbol wave.  A DynProb is
+// packed into 32 bits (two 10-bit counts and the probability the next decision will use, which is NOT derivable from the counts
+// after a rescale), biased so that zero-filled memory is the initial state.  See DESIGN.md section 4.3.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/lh264.h"
