@@ -133,7 +133,6 @@ struct Coder {
   uint32_t cur_key, cur_slot; bool have_cell;
   uint32_t test_prob;      // TEST_PROB, wave-uniform
   int status;
-  Bc bc;                   // this lane's tag
   STAMP_FIELDS
   Handoff* H; int buf;        // hand-off buffers (LDS) and the one to fill next
 };
@@ -167,11 +166,6 @@ __device__ __forceinline__ void cell_get (Coder& c, uint32_t key) {
   }
   c.status = 1;             // table full
   c.cur_key = key; c.cur_slot = 0; c.have_cell = false; c.cellv = 0;
-}
-
-__device__ __forceinline__ void touch_tag (Coder& c, int tag) {       // a stream exists once tag() was called for it
-  const int slot = tag_slot (tag);
-  if (c.lane == slot && !c.bc.used) { c.bc.low = 0; c.bc.range = 255; c.bc.count = -24; c.bc.pos = 0; c.bc.ffrun = 0; c.bc.pending = -1; c.bc.used = 1; c.bc.last = 0; }
 }
 
 // ---- binarisation: a symbol becomes a short list of decisions ---------------------------------------------------------------
