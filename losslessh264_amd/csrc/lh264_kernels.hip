@@ -633,6 +633,32 @@ __device__ __forceinline__ Row12 align12 (v4u d, int sh) {
 // byte i (0..11, compile-time) of a Row12
 #define RB(R, i) ((i) < 4 ? BYTE ((R).w0, (i)) : (i) < 8 ? BYTE ((R).w1, (i) - 4) : BYTE ((R).w2, (i) - 8))
 
+// The 6-tap filter (1,-5,20,20,-5,1) on bytes without unpacking them one by one.
+// Horizontal: the six samples of an output are consecutive bytes - two signed 4x8-bit dot products (v_dot4c_i32_i8) on the row
+// with 128 subtracted from every sample (the taps sum to 32, so 4096 goes back in).  Vertical: the same byte position of six
+// rows - the rows are split into two 2x16-bit words each (even / odd bytes) and the filter runs on 16-bit pairs (v_pk_*); the
+// sums stay within int16 (|sum| <= 10,710).
+typedef short s16x2 __attribute__ ((ext_vector_type (2)));
+__device__ __forceinline__ s16x2 as_s2 (uint32_t v) { return __builtin_bit_cast (s16x2, v); }
+__device__ __forceinline__ uint32_t as_u (s16x2 v) { return __builtin_bit_cast (uint32_t, v); }
+// horizontal taps at outputs 0..3 of a row (output i = samples i..i+5)
+__device__ __forceinline__ void htap4 (const Row12 R, int out[4]) {
+  const uint32_t s0 = R.w0 ^ 0x80808080u, s1 = R.w1 ^ 0x80808080u, s2 = R.w2 ^ 0x80808080u;
+  const int ca = 0x1414FB01, cb = 0x000001FB;       // bytes (1, -5, 20, 20) and (-5, 1, 0, 0)
+  out[0] = __builtin_amdgcn_sdot4 ((int)s0, ca, __builtin_amdgcn_sdot4 ((int)s1, cb, 4096, false), false);
+#pragma unroll
+  for (int i = 1; i < 4; i++)
+    out[i] = __builtin_amdgcn_sdot4 ((int)__builtin_amdgcn_alignbyte (s1, s0, i), ca,
+                                     __builtin_amdgcn_sdot4 ((int)__builtin_amdgcn_alignbyte (s2, s1, i), cb, 4096, false), false);
+}
+// vertical taps of the byte positions of one word of six rows: even bytes (0, 2) in e, odd bytes (1, 3) in o, as 16-bit pairs
+__device__ __forceinline__ void vtap_word (uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t r4, uint32_t r5, s16x2& e, s16x2& o) {
+  const uint32_t M = 0x00ff00ffu;
+  const s16x2 k20 = {20, 20}, k5 = {5, 5};
+  e = (as_s2 (r2 & M) + as_s2 (r3 & M)) * k20 + (as_s2 (r0 & M) + as_s2 (r5 & M)) - (as_s2 (r1 & M) + as_s2 (r4 & M)) * k5;
+  o = (as_s2 ((r2 >> 8) & M) + as_s2 ((r3 >> 8) & M)) * k20 + (as_s2 ((r0 >> 8) & M) + as_s2 ((r5 >> 8) & M)) - (as_s2 ((r1 >> 8) & M) + as_s2 ((r4 >> 8) & M)) * k5;
+}
+
 // one 4x1 luma strip from the fetched rows: R[k] holds samples -2..9 of row k-2 relative to the strip's first sample
 // (McLuma_c / McHorVer* common/src/mc.cpp:142-380).  With fy == 0 only R[2] is defined.
 __device__ __forceinline__ void mc_luma_rows (const Row12 R[6], int fx, int fy, int out[4]) {
@@ -642,37 +668,49 @@ __device__ __forceinline__ void mc_luma_rows (const Row12 R[6], int fx, int fy, 
     return;
   }
   if (fy == 0) {                      // a, b, c : one row
+    int t[4];
+    htap4 (R[2], t);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int b = clip_u8 ((tap6 (RB (R[2], i), RB (R[2], i + 1), RB (R[2], i + 2), RB (R[2], i + 3), RB (R[2], i + 4), RB (R[2], i + 5)) + 16) >> 5);
+      const int b = clip_u8 ((t[i] + 16) >> 5);
       out[i] = fx == 2 ? b : (b + (fx == 1 ? RB (R[2], i + 2) : RB (R[2], i + 3)) + 1) >> 1;
     }
     return;
   }
-  if (fx == 0) {                      // d, h, n : six rows, samples 0..3
+  if (fx == 0) {                      // d, h, n : six rows, samples 0..3 = bytes 2..5
+    s16x2 e, o;
+    vtap_word (__builtin_amdgcn_alignbyte (R[0].w1, R[0].w0, 2), __builtin_amdgcn_alignbyte (R[1].w1, R[1].w0, 2), __builtin_amdgcn_alignbyte (R[2].w1, R[2].w0, 2),
+               __builtin_amdgcn_alignbyte (R[3].w1, R[3].w0, 2), __builtin_amdgcn_alignbyte (R[4].w1, R[4].w0, 2), __builtin_amdgcn_alignbyte (R[5].w1, R[5].w0, 2), e, o);
+    const int t[4] = {e.x, o.x, e.y, o.y};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int h = clip_u8 ((tap6 (RB (R[0], i + 2), RB (R[1], i + 2), RB (R[2], i + 2), RB (R[3], i + 2), RB (R[4], i + 2), RB (R[5], i + 2)) + 16) >> 5);
+      const int h = clip_u8 ((t[i] + 16) >> 5);
       out[i] = fy == 2 ? h : (h + (fy == 1 ? RB (R[2], i + 2) : RB (R[3], i + 2)) + 1) >> 1;
     }
     return;
   }
   // both fractions: vertical 6-tap sums of the 9 columns -2..6 (int16, as the reference keeps them)
   int vs[9];
-#pragma unroll
-  for (int c = 0; c < 9; c++) vs[c] = tap6 (RB (R[0], c), RB (R[1], c), RB (R[2], c), RB (R[3], c), RB (R[4], c), RB (R[5], c));
+  {
+    s16x2 e0, o0, e1, o1, e2, o2;
+    vtap_word (R[0].w0, R[1].w0, R[2].w0, R[3].w0, R[4].w0, R[5].w0, e0, o0);
+    vtap_word (R[0].w1, R[1].w1, R[2].w1, R[3].w1, R[4].w1, R[5].w1, e1, o1);
+    vtap_word (R[0].w2, R[1].w2, R[2].w2, R[3].w2, R[4].w2, R[5].w2, e2, o2);
+    vs[0] = e0.x; vs[1] = o0.x; vs[2] = e0.y; vs[3] = o0.y; vs[4] = e1.x; vs[5] = o1.x; vs[6] = e1.y; vs[7] = o1.y; vs[8] = e2.x;
+  }
   int hh[4];                          // horizontal half-sample of window row 2 (fy==1,2) or 3 (fy==3)
   Row12 H = R[2];
   if (fy == 3) H = R[3];
+  htap4 (H, hh);
 #pragma unroll
-  for (int i = 0; i < 4; i++) hh[i] = clip_u8 ((tap6 (RB (H, i), RB (H, i + 1), RB (H, i + 2), RB (H, i + 3), RB (H, i + 4), RB (H, i + 5)) + 16) >> 5);
+  for (int i = 0; i < 4; i++) hh[i] = clip_u8 ((hh[i] + 16) >> 5);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int c = i + 2;
     const int vv0 = clip_u8 ((vs[c] + 16) >> 5), vv1 = clip_u8 ((vs[c + 1] + 16) >> 5);
     int v;
     if (fx == 2 || fy == 2) {
-      const int j = clip_u8 ((tap6 (sext16 (vs[c - 2]), sext16 (vs[c - 1]), sext16 (vs[c]), sext16 (vs[c + 1]), sext16 (vs[c + 2]), sext16 (vs[c + 3])) + 512) >> 10);
+      const int j = clip_u8 ((tap6 (vs[c - 2], vs[c - 1], vs[c], vs[c + 1], vs[c + 2], vs[c + 3]) + 512) >> 10);
       if (fx == 2 && fy == 2) v = j;
       else if (fx == 2) v = (j + hh[i] + 1) >> 1;          // f, q
       else v = (j + (fx == 1 ? vv0 : vv1) + 1) >> 1;       // i, k
