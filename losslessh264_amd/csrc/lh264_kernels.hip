@@ -723,9 +723,10 @@ __device__ __forceinline__ void mc_luma_rows (const Row12 R[6], int fx, int fy, 
 // 4 bytes starting at the pair's first sample in rows 0 / 1 (McChroma_c mc.cpp)
 __device__ __forceinline__ void mc_chroma_rows (uint32_t a, uint32_t b, int dx, int dy, int& o0, int& o1) {
   if ((dx | dy) == 0) { o0 = BYTE (a, 0); o1 = BYTE (a, 1); return; }
-  const int A = (8 - dx) * (8 - dy), B = dx * (8 - dy), Cc = (8 - dx) * dy, D = dx * dy;
-  o0 = (A * BYTE (a, 0) + B * BYTE (a, 1) + Cc * BYTE (b, 0) + D * BYTE (b, 1) + 32) >> 6;
-  o1 = (A * BYTE (a, 1) + B * BYTE (a, 2) + Cc * BYTE (b, 1) + D * BYTE (b, 2) + 32) >> 6;
+  // the four weights (each <= 64) as bytes, the four samples of an output as bytes: one unsigned 4x8-bit dot product each
+  const uint32_t wgt = (uint32_t) ((8 - dx) * (8 - dy)) | (uint32_t) (dx * (8 - dy)) << 8 | (uint32_t) ((8 - dx) * dy) << 16 | (uint32_t) (dx * dy) << 24;
+  o0 = (int) (__builtin_amdgcn_udot4 ((a & 0xffffu) | (b << 16), wgt, 32u, false) >> 6);
+  o1 = (int) (__builtin_amdgcn_udot4 (((a >> 8) & 0xffffu) | ((b >> 8) << 16), wgt, 32u, false) >> 6);
 }
 
 // partition geometry of the 4x4 block (bx,by): origin and size of the motion partition that holds it
