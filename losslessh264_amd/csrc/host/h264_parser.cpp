@@ -3,6 +3,9 @@
 // group -- the subset the reference decoder itself supports.
 #include "h264_parser.h"
 #include <mutex>
+#include <atomic>
+#include <thread>
+#include <functional>
 #include "pip_symbols.h"
 #include "h264_cabac_tables.h"
 #include <string.h>
@@ -29,12 +32,25 @@ struct SharedZeroPool {
   }
   bool put (void* p, size_t b) {
     std::lock_guard<std::mutex> g (m);
-    if (bytes + b > ((size_t)4 << 30)) return false;
+    if (bytes + b > ((size_t)4 << 30) / 16) return false;
     by_size[b].push_back (p); bytes += b;
     return true;
   }
 };
-SharedZeroPool& shared_pool() { static SharedZeroPool p; return p; }
+// sixteen of them: released blocks are dealt round robin, a thread looks in "its" shard first - the pictures of a batch are
+// released by one thread and taken by sixteen, and one lock would serialise them
+enum { kShards = 16 };
+struct ShardedPool {
+  SharedZeroPool shard[kShards];
+  std::atomic<unsigned> rr {0};
+  void* get (size_t b) {
+    static thread_local unsigned mine = (unsigned)std::hash<std::thread::id>() (std::this_thread::get_id());
+    for (unsigned i = 0; i < kShards; i++) if (void* p = shard[(mine + i) % kShards].get (b)) return p;
+    return nullptr;
+  }
+  bool put (void* p, size_t b) { return shard[rr.fetch_add (1, std::memory_order_relaxed) % kShards].put (p, b); }
+};
+ShardedPool& shared_pool() { static ShardedPool p; return p; }
 struct ZeroCache {
   enum { kKeep = 256 };
   struct E { void* p; size_t bytes; } e[kKeep];
@@ -160,7 +176,20 @@ struct Parser::Impl {
   int slice_cached_qp = 0, slice_run_before = 0;
   Symbolizer symbolizer;
   int last_hdr_bits = -1; bool last_cabac = false;
-  int16_t no_coef[384];                                  // where the dequantised coefficients go when nobody wants them       // the slice NAL just handled: header length in bits, entropy mode
+  int16_t no_coef[384];                                  // where the dequantised coefficients go when nobody wants them
+  int16_t lev_scratch[384];                              // sparse mode: the macroblock in hand, turned into list entries when it is done
+  // a coded macroblock is done: note whether it has any nonzero level; in sparse mode list them (picture-relative index << 16 | value)
+  void finish_levels (int k) {
+    const int16_t* lv = self->sparse_levels_ ? lev_scratch : &cur->levels[(size_t)k * 384];
+    const uint64_t* q = (const uint64_t*)lv;
+    bool any = false;
+    for (int i = 0; i < 96; i++) if (q[i]) {
+        any = true;
+        if (!self->sparse_levels_) break;
+        for (int j = 0; j < 4; j++) { const int16_t v = lv[4 * i + j]; if (v) cur->sparse.push_back (((uint64_t) ((size_t)k * 384 + 4 * i + j) << 16) | (uint16_t)v); }
+      }
+    cur->lev_nonzero[k] = any ? 1 : 0;
+  }       // the slice NAL just handled: header length in bits, entropy mode
 
   explicit Impl (Parser* s) : self (s) {}
 
@@ -460,7 +489,8 @@ struct Parser::Impl {
     const size_t n = (size_t)S.mb_w * S.mb_h;
     cur->mbs.assign (n, lh264_mb_t()); memset (cur->mbs.data(), 0, n * sizeof (lh264_mb_t));
     if (self->want_coeffs_) cur->coeffs.assign_zero ((size_t)n * 384);
-    cur->levels.assign_zero ((size_t)n * 384, !self->lazy_levels_); cur->covered.assign (n, 0);
+    if (!self->sparse_levels_) cur->levels.assign_zero ((size_t)n * 384, !self->lazy_levels_);
+    cur->lev_nonzero.assign (n, 0); cur->covered.assign (n, 0);
     cur->syn.assign (n, MbSyn()); memset (cur->syn.data(), 0, n * sizeof (MbSyn));
     if (persist_w != S.mb_w || persist_h != S.mb_h) {       // the decoder re-allocates (zeroed) on a resolution change
       persist_w = S.mb_w; persist_h = S.mb_h;
@@ -739,8 +769,8 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
   for (int i = 0; i < 16; i++) { s.ipm[i] = 2; s.mv[i][0] = s.mv[i][1] = 0; }
   for (int i = 0; i < 4; i++) { s.ref[i] = -1; m.ref_idx[i] = -1; }
   int16_t* coef = self->want_coeffs_ ? &cur->coeffs[(size_t)k * 384] : no_coef;
-  int16_t* lev = &cur->levels[(size_t)k * 384];
-  if (self->lazy_levels_ && !is_skip) memset (lev, 0, 768);
+  int16_t* lev = self->sparse_levels_ ? lev_scratch : &cur->levels[(size_t)k * 384];
+  if ((self->lazy_levels_ || self->sparse_levels_) && !is_skip) memset (lev, 0, 768);
   const bool use_sl = S.scaling_matrix_present || P.scaling_matrix_present;
   auto set_qp = [&] (int qp) {
     m.qp_y = (uint8_t)qp;
@@ -782,6 +812,7 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
       memcpy (y.sub_type, &d->persist_sub[(size_t)k * 4], 4);
       y.delta_qp = (int)m.qp_y - d->slice_cached_qp;
       d->slice_cached_qp = m.qp_y;
+      if (m.mb_type != LH264_MB_IPCM) d->finish_levels (k);
     }
   } syn_done = {this, y, m, k};
   uint32_t mbt = br.ue();
@@ -1086,8 +1117,8 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
   for (int i = 0; i < 4; i++) { s.ref[i] = -1; m.ref_idx[i] = -1; }
   s.skip = 0; s.pcm = 0; s.t8 = 0; s.cbp = 0; s.chroma_pred = 0; s.cbf = 0;
   int16_t* coef = self->want_coeffs_ ? &cur->coeffs[(size_t)k * 384] : no_coef;
-  int16_t* lev = &cur->levels[(size_t)k * 384];
-  if (self->lazy_levels_ && !is_skip) memset (lev, 0, 768);
+  int16_t* lev = self->sparse_levels_ ? lev_scratch : &cur->levels[(size_t)k * 384];
+  if ((self->lazy_levels_ || self->sparse_levels_) && !is_skip) memset (lev, 0, 768);
   const bool use_sl = S.scaling_matrix_present || P.scaling_matrix_present;
   const int kA = ((k % w) && mb_avail (k - 1, sid)) ? k - 1 : -1, kB = (k >= w && mb_avail (k - w, sid)) ? k - w : -1;
   auto set_qp = [&] (int qp) {
@@ -1132,6 +1163,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
       memcpy (y.sub_type, &d->persist_sub[(size_t)k * 4], 4);
       y.delta_qp = (int)m.qp_y - d->slice_cached_qp;
       d->slice_cached_qp = m.qp_y;
+      if (m.mb_type != LH264_MB_IPCM) d->finish_levels (k);
     }
   } syn_done = {this, y, m, k};
 

@@ -168,6 +168,8 @@ struct FrameOut {
   std::vector<SliceSyn> slice_syn;      // per slice
   PoolVec<lh264_ctx_sym_t> syn_syms;       // the picture's row-a10 symbols (Symbolizer), macroblock after macroblock
   PoolVec<uint32_t> syn_off;               // mb_w*mb_h + 1 offsets
+  PoolVec<uint8_t> lev_nonzero;            // per macroblock: it has a nonzero level (FreqImage's 'zeroed' test)
+  PoolVec<uint64_t> sparse;                // sparse mode instead of `levels`: (macroblock * 384 + position) << 16 | level, nonzero levels only
 };
 
 // The recompressor's default stream (".pip" itself, stream id 0x7fffffff): the Annex-B input minus its slice data.
@@ -228,6 +230,9 @@ class Parser {
   // lazy == true: FrameOut::levels is cleared macroblock by macroblock as coded macroblocks are parsed; the levels of skipped
   // or lost macroblocks are then undefined (no kernel reads them: lh264_ctx.hip returns on their type)
   void set_lazy_levels (bool lazy) { lazy_levels_ = lazy; }
+  // sparse == true: FrameOut::levels stays empty and FrameOut::sparse lists the nonzero levels (a few per macroblock instead of
+  // 768 bytes: what travels to the device, where lh264_compress_batch expands it)
+  void set_sparse_levels (bool sparse) { sparse_levels_ = sparse; }
   long pictures_done() const { return pictures_done_; }
 
  private:
@@ -236,7 +241,7 @@ class Parser {
   std::vector<std::unique_ptr<FrameOut>> frames_;
   std::string err_;
   int n_unsupported_ = 0;
-  bool keep_frames_ = true, want_coeffs_ = true, lazy_levels_ = false; long pictures_done_ = 0;
+  bool keep_frames_ = true, want_coeffs_ = true, lazy_levels_ = false, sparse_levels_ = false; long pictures_done_ = 0;
   MainStreamWriter main_;
   friend struct Impl;
 };

@@ -223,9 +223,7 @@ void Symbolizer::picture (FrameOut& f) {
       Cell e;
       e.initialized = 1; e.cbp_c = R.cbp_c; e.cbp_l = R.cbp_l; e.chroma_mode = R.chroma_mode; e.luma16_mode = R.luma16_mode;
       e.mb_type = type; e.num_ref = R.num_ref_idx_l0; e.cached_skips = 0;
-      e.zeroed = 1;
-      const int16_t* lv = &f.levels[(size_t)k * 384];
-      for (int i = 0; i < 384; i++) if (lv[i]) { e.zeroed = 0; break; }
+      e.zeroed = f.lev_nonzero[k] ? 0 : 1;
       cur[k] = e;
     }
     // the alignment bits after the slice's stop bit go to the pad-byte tag, DS:3133-3148

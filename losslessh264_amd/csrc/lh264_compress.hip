@@ -35,6 +35,12 @@ __global__ void __launch_bounds__ (256) pack_tags_kernel (const PackItem* __rest
   for (uint32_t i = threadIdx.x; i < it.len; i += blockDim.x) d[i] = s[i];
 }
 
+// the raw levels travel as a list of the nonzero ones: (index into the group's level planes) << 16 | level
+__global__ void __launch_bounds__ (256) expand_levels_kernel (const uint64_t* __restrict__ ents, size_t n, int16_t* __restrict__ dense) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const uint64_t e = ents[i]; dense[e >> 16] = (int16_t) (uint16_t) (e & 0xffffu); }
+}
+
 namespace {
 
 static bool trace_on() { static const bool t = getenv ("LH264_TRACE_COMPRESS") != nullptr; return t; }
@@ -72,7 +78,8 @@ struct PinBuf {                       // page-locked staging memory (the upload 
 };
 struct Arena {
   DevBuf d_mbs, d_lev, d_sl, d_nnz, d_syms, d_nsyms, d_cj, d_first, d_syn, d_off, d_kj, d_st, d_keys, d_cells, d_out, d_len, d_items, d_packed;
-  PinBuf h_mbs, h_lev, h_sl, h_syn, h_off, h_packed;
+  PinBuf h_mbs, h_sparse, h_sl, h_syn, h_off, h_packed;
+  DevBuf d_sparse;
 };
 
 // which earlier picture the reference's FreqImage holds as PAST (decoded_macroblock.h:119-123): two buffers, flipped when
@@ -97,17 +104,19 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   using lh264host::FrameOut;
   const int n_chains = (int)idx.size();
   // where every stream's records go
-  std::vector<size_t> mb0 (n_chains + 1, 0), sl0 (n_chains + 1, 0), sy0 (n_chains + 1, 0), of0 (n_chains + 1, 0), jb0 (n_chains + 1, 0);
+  std::vector<size_t> mb0 (n_chains + 1, 0), sl0 (n_chains + 1, 0), sy0 (n_chains + 1, 0), of0 (n_chains + 1, 0), jb0 (n_chains + 1, 0), sp0 (n_chains + 1, 0);
   int max_mbs = 1;
   for (int c = 0; c < n_chains; c++) {
-    size_t m = 0, sl = 0, sy = 0, of = 0, jb = 0;
+    size_t m = 0, sl = 0, sy = 0, of = 0, jb = 0, sp = 0;
     for (auto& f : parsers[idx[c]]->frames()) {
       const size_t n = (size_t)f->mb_w * f->mb_h;
-      m += n; sl += f->slices.size(); sy += f->syn_syms.size(); of += n + 1; jb++;
+      m += n; sl += f->slices.size(); sy += f->syn_syms.size(); of += n + 1; jb++; sp += f->sparse.size();
       max_mbs = std::max (max_mbs, (int)n);
     }
+    sp0[c + 1] = sp0[c] + sp;
     mb0[c + 1] = mb0[c] + m; sl0[c + 1] = sl0[c] + sl; sy0[c + 1] = sy0[c] + sy; of0[c + 1] = of0[c] + of; jb0[c + 1] = jb0[c] + jb;
   }
+  const size_t n_sparse = sp0[n_chains];
   const size_t n_mbs = mb0[n_chains], n_slices = sl0[n_chains], n_syn = sy0[n_chains], n_off = of0[n_chains], n_jobs = jb0[n_chains];
   if (n_jobs == 0) return;
   std::vector<lh264_ctx_job_t> h_cj (n_jobs);
@@ -126,22 +135,22 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   }
   const size_t keys_total = key0[n_chains], out_total = out0[n_chains];
   const double t_a = now_s();
-  const bool ok = A.d_mbs.alloc (n_mbs * sizeof (lh264_mb_t), false) && A.d_lev.alloc (n_mbs * 768, false) && A.d_sl.alloc (n_slices * sizeof (lh264_slice_t), false) &&
+  const bool ok = A.d_mbs.alloc (n_mbs * sizeof (lh264_mb_t), false) && A.d_lev.alloc (n_mbs * 768, true) && A.d_sparse.alloc (n_sparse * 8, false) && A.d_sl.alloc (n_slices * sizeof (lh264_slice_t), false) &&
                   A.d_nnz.alloc (n_mbs * 24, true) && A.d_syms.alloc (n_mbs * LH264_CTX_MAX_SYMS * sizeof (lh264_ctx_sym_t), false) && A.d_nsyms.alloc (n_mbs * 2, true) &&
                   A.d_cj.alloc (n_jobs * sizeof (lh264_ctx_job_t), false) && A.d_first.alloc ((n_chains + 1) * 4, false) && A.d_syn.alloc (n_syn * sizeof (lh264_ctx_sym_t), false) &&
                   A.d_off.alloc (n_off * 4, false) && A.d_kj.alloc (n_jobs * sizeof (lh264_code_job_t), false) && A.d_st.alloc (n_chains * sizeof (lh264_code_stream_t), false) &&
                   A.d_keys.alloc (keys_total * 4, true) && A.d_cells.alloc (keys_total * 64, true) && A.d_out.alloc (out_total, false) &&
                   A.d_len.alloc ((size_t)n_chains * (LH264_N_TAG_SLOTS + 1) * 4, true) &&
-                  A.h_mbs.alloc (n_mbs * sizeof (lh264_mb_t)) && A.h_lev.alloc (n_mbs * 768) && A.h_sl.alloc (n_slices * sizeof (lh264_slice_t)) &&
+                  A.h_mbs.alloc (n_mbs * sizeof (lh264_mb_t)) && A.h_sparse.alloc (n_sparse * 8) && A.h_sl.alloc (n_slices * sizeof (lh264_slice_t)) &&
                   A.h_syn.alloc (n_syn * sizeof (lh264_ctx_sym_t)) && A.h_off.alloc (n_off * 4);
   if (!ok) { fail_all (out, idx, LH264_E_HIP, "device allocation failed"); return; }
   const double t_b = now_s();
-  lh264_mb_t* h_mbs = A.h_mbs.as<lh264_mb_t>(); int16_t* h_lev = A.h_lev.as<int16_t>(); lh264_slice_t* h_sl = A.h_sl.as<lh264_slice_t>();
+  lh264_mb_t* h_mbs = A.h_mbs.as<lh264_mb_t>(); uint64_t* h_sparse = A.h_sparse.as<uint64_t>(); lh264_slice_t* h_sl = A.h_sl.as<lh264_slice_t>();
   lh264_ctx_sym_t* h_syn = A.h_syn.as<lh264_ctx_sym_t>(); uint32_t* h_off = A.h_off.as<uint32_t>();
   // staging: every stream copies its pictures to its place (host threads), and writes its job records
   run_parallel (n_chains, threads, [&] (int c) {
     auto& fr = parsers[idx[c]]->frames();
-    size_t mo = mb0[c], so = sl0[c], yo = sy0[c], oo = of0[c], j = jb0[c];
+    size_t mo = mb0[c], so = sl0[c], yo = sy0[c], oo = of0[c], j = jb0[c], po = sp0[c];
     h_first[c] = (int32_t)j;
     std::vector<int> past;
     past_policy (fr, past);
@@ -151,7 +160,7 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
       const size_t n = (size_t)f.mb_w * f.mb_h;
       mb_at[i] = mo;
       memcpy (&h_mbs[mo], f.mbs.data(), n * sizeof (lh264_mb_t));
-      memcpy (&h_lev[mo * 384], f.levels.data(), n * 768);
+      { const uint64_t add = (uint64_t) (mo * 384) << 16; const size_t ns = f.sparse.size(); for (size_t q = 0; q < ns; q++) h_sparse[po + q] = f.sparse[q] + add; po += ns; }
       if (!f.slices.empty()) memcpy (&h_sl[so], f.slices.data(), f.slices.size() * sizeof (lh264_slice_t));
       if (!f.syn_syms.empty()) memcpy (&h_syn[yo], f.syn_syms.data(), f.syn_syms.size() * sizeof (lh264_ctx_sym_t));
       memcpy (&h_off[oo], f.syn_off.data(), (n + 1) * 4);
@@ -174,11 +183,12 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   h_first[n_chains] = (int32_t)n_jobs;
   const double t_c = now_s();
   auto up = [] (DevBuf& d, const void* s, size_t bytes) { return bytes == 0 || hipMemcpyAsync (d.p, s, bytes, hipMemcpyHostToDevice, nullptr) == hipSuccess; };
-  if (!(up (A.d_mbs, h_mbs, n_mbs * sizeof (lh264_mb_t)) && up (A.d_lev, h_lev, n_mbs * 768) && up (A.d_sl, h_sl, n_slices * sizeof (lh264_slice_t)) &&
+  if (!(up (A.d_mbs, h_mbs, n_mbs * sizeof (lh264_mb_t)) && up (A.d_sparse, h_sparse, n_sparse * 8) && up (A.d_sl, h_sl, n_slices * sizeof (lh264_slice_t)) &&
         up (A.d_syn, h_syn, n_syn * sizeof (lh264_ctx_sym_t)) && up (A.d_off, h_off, n_off * 4) && up (A.d_cj, h_cj.data(), n_jobs * sizeof (lh264_ctx_job_t)) &&
         up (A.d_kj, h_kj.data(), n_jobs * sizeof (lh264_code_job_t)) && up (A.d_first, h_first.data(), (n_chains + 1) * 4) && up (A.d_st, h_st.data(), n_chains * sizeof (lh264_code_stream_t)))) {
     fail_all (out, idx, LH264_E_HIP, "upload failed"); return;
   }
+  if (n_sparse) hipLaunchKernelGGL (expand_levels_kernel, dim3 ((unsigned) ((n_sparse + 255) / 256)), dim3 (256), 0, nullptr, A.d_sparse.as<uint64_t>(), n_sparse, A.d_lev.as<int16_t>());
   if (trace_on()) hipDeviceSynchronize();
   const double t_d = now_s();
   int rc = lh264_ctx_index_chains (A.d_cj.as<lh264_ctx_job_t>(), A.d_first.as<int32_t>(), n_chains, (int)n_jobs, max_mbs, nullptr);
@@ -265,7 +275,7 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
       const int i = w0 + k;
       parsers[i].reset (new lh264host::Parser());
       parsers[i]->set_want_coeffs (false);
-      parsers[i]->set_lazy_levels (true);
+      parsers[i]->set_sparse_levels (true);
       if (data[i] || !len[i]) parsers[i]->feed_file (data[i], len[i]);
     });
     if (trace_on()) fprintf (stderr, "[lh264 compress] wave of %d streams parsed in %.3f s\n", w1 - w0, now_s() - t_p);
