@@ -73,6 +73,20 @@ void zerobuf_put (void* p, size_t bytes) {
   else if (bytes < 4096 || !shared_pool().put (p, bytes)) free (p);
 }
 
+StreamArena*& current_stream_arena() { static thread_local StreamArena* a = nullptr; return a; }
+StreamArena::~StreamArena() { for (auto& c : chunks) zerobuf_put (c.first, c.second); }
+void* StreamArena::alloc (size_t bytes) {
+  bytes = (bytes + 63) & ~ (size_t)63;
+  if (chunks.empty() || used + bytes > chunks.back().second) {
+    const size_t cap = std::max<size_t> ((size_t)1 << 20, bytes);
+    chunks.emplace_back ((char*)zerobuf_get (cap, false), cap);
+    used = 0;
+  }
+  void* p = chunks.back().first + used;
+  used += bytes;
+  return p;
+}
+
 bool BitReader::more_rbsp_data() const {
   if (pos >= nbits) return false;
   // find the last set bit of the payload (the rbsp stop bit)
@@ -1627,6 +1641,7 @@ void MainStreamWriter::stop_escape() {
 // zero bytes (au_parser.cpp:588), one zero byte per trailing zero byte (decoder.cpp:610-627), for a slice the bits of its
 // header (decode_slice.cpp:2974-2980) and, for CAVLC, a single 1 bit (decoder.cpp:837-845); zero bits up to the byte.
 int Parser::feed_file (const uint8_t* d, size_t n) {
+  struct Scope { StreamArena*& slot; StreamArena* prev; Scope (StreamArena* a) : slot (current_stream_arena()), prev (slot) { slot = a; } ~Scope() { slot = prev; } } scope (arena_.get());
   int rc = 0;
   size_t pos = 0;
   std::vector<uint8_t> nal;

@@ -141,13 +141,32 @@ template <typename T> class ZeroBuf {
 // std::vector on the same recycled blocks (sizes rounded up to 4 KB so that pictures of one stream reuse each other's blocks):
 // the per-picture arrays of a batch are released by another thread than the one that parses the next streams, and handing
 // them to the C library means trimmed heaps and fresh page faults for every wave of streams
+// A parser can also carve the small per-picture arrays out of megabyte chunks of its own (StreamArena, set while it parses):
+// nothing is returned block by block then - the chunks go back when the parser is destroyed - which is what keeps the release
+// of a batch's pictures from competing with the parsing of the next ones.  A 16-byte header in front of every block says
+// where it came from.
+struct StreamArena {
+  std::vector<std::pair<char*, size_t>> chunks;
+  size_t used = 0;
+  ~StreamArena();
+  void* alloc (size_t bytes);
+};
+StreamArena*& current_stream_arena();               // thread local
 template <typename T> struct PoolAlloc {
   typedef T value_type;
   PoolAlloc() {}
   template <typename U> PoolAlloc (const PoolAlloc<U>&) {}
-  static size_t round (size_t n) { return ((n * sizeof (T)) + 4095) & ~ (size_t)4095; }
-  T* allocate (size_t n) { return (T*)zerobuf_get (round (n), false); }
-  void deallocate (T* p, size_t n) { zerobuf_put (p, round (n)); }
+  static size_t round (size_t n) { return ((n * sizeof (T)) + 16 + 4095) & ~ (size_t)4095; }
+  T* allocate (size_t n) {
+    char* p;
+    if (StreamArena* a = current_stream_arena()) { p = (char*)a->alloc (n * sizeof (T) + 16); * (uint64_t*)p = 1; }
+    else { p = (char*)zerobuf_get (round (n), false); * (uint64_t*)p = 0; }
+    return (T*) (p + 16);
+  }
+  void deallocate (T* q, size_t n) {
+    char* p = (char*)q - 16;
+    if (* (uint64_t*)p == 0) zerobuf_put (p, round (n));
+  }
   template <typename U> bool operator== (const PoolAlloc<U>&) const { return true; }
   template <typename U> bool operator!= (const PoolAlloc<U>&) const { return false; }
 };
@@ -233,10 +252,13 @@ class Parser {
   // sparse == true: FrameOut::levels stays empty and FrameOut::sparse lists the nonzero levels (a few per macroblock instead of
   // 768 bytes: what travels to the device, where lh264_compress_batch expands it)
   void set_sparse_levels (bool sparse) { sparse_levels_ = sparse; }
+  // on: the per-picture arrays come from chunks owned by this parser (see StreamArena)
+  void set_stream_arena (bool on) { if (on && !arena_) arena_.reset (new StreamArena()); else if (!on) arena_.reset(); }
   long pictures_done() const { return pictures_done_; }
 
  private:
   struct Impl;
+  std::unique_ptr<StreamArena> arena_;      // declared first: destroyed after the pictures that live in it
   std::unique_ptr<Impl> d_;
   std::vector<std::unique_ptr<FrameOut>> frames_;
   std::string err_;

@@ -262,7 +262,8 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
     if (running.empty()) return;
     device_thread = std::thread ([&, device] () {
       hipSetDevice (device);
-      compress_group (arena, parsers, running, len, out, std::max (1, threads / 2));
+      if (!getenv ("LH264_COMPRESS_PARSE_ONLY"))          // diagnostic: the host side alone
+        compress_group (arena, parsers, running, len, out, std::max (1, threads / 2));
       for (int i : running) parsers[i].reset();          // the pictures go back to the pool while the next wave is parsed
     });
   };
@@ -276,6 +277,7 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
       parsers[i].reset (new lh264host::Parser());
       parsers[i]->set_want_coeffs (false);
       parsers[i]->set_sparse_levels (true);
+      parsers[i]->set_stream_arena (true);
       if (data[i] || !len[i]) parsers[i]->feed_file (data[i], len[i]);
     });
     if (trace_on()) fprintf (stderr, "[lh264 compress] wave of %d streams parsed in %.3f s\n", w1 - w0, now_s() - t_p);
