@@ -270,7 +270,7 @@ int lh264_pip_restore_file (const uint8_t* file, size_t len, uint8_t* out, size_
 }
 int lh264_parse_batch (const uint8_t* const* data, const size_t* len, int n, int threads, lh264_parser_t** parsers_out) {
   if (!data || !len || !parsers_out || n < 0) return LH264_E_ARG;
-  for (int i = 0; i < n; i++) parsers_out[i] = new lh264_parser();
+  for (int i = 0; i < n; i++) { parsers_out[i] = new lh264_parser(); parsers_out[i]->p.set_stream_arena (true); }
   run_parallel (n, threads, [&] (int i) { if (data[i] || !len[i]) parsers_out[i]->p.feed_file (data[i], len[i]); });
   return LH264_OK;
 }
