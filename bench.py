@@ -223,8 +223,14 @@ def main():
             et = time.perf_counter() - t0
             assert all(e is None for _, _, e in e2e) and e2e[-1][1] == tags and e2e[-1][0] == main_stream
             del e2e
+            t0 = time.perf_counter()
+            e2e = lh.compress_batch([data] * (16 * nb), ncpu)          # four groups: parsing overlaps the device stage
+            et4 = time.perf_counter() - t0
+            assert all(e is None for _, _, e in e2e) and e2e[-1][1] == tags
+            del e2e
             roundtrip["host_stages"] = {"threads": ncpu, "streams": nb, "front_end_MB_per_s": nb * stream_bytes / pt / 1e6,
                                         "compress_batch_end_to_end_MB_per_s": 4 * nb * stream_bytes / et / 1e6, "compress_batch_streams": 4 * nb,
+                                        "compress_batch_end_to_end_%d_streams_MB_per_s" % (16 * nb): 16 * nb * stream_bytes / et4 / 1e6,
                                         "front_end_keep_all_MB_per_s": nb * stream_bytes / pk / 1e6,
                                         "restore_MB_per_s": nb * stream_bytes / rt / 1e6}
         coder_info["roundtrip"] = roundtrip
