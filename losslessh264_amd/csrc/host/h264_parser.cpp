@@ -191,17 +191,19 @@ struct Parser::Impl {
   Symbolizer symbolizer;
   int last_hdr_bits = -1; bool last_cabac = false;
   int16_t no_coef[384];                                  // where the dequantised coefficients go when nobody wants them
-  int16_t lev_scratch[384];                              // sparse mode: the macroblock in hand, turned into list entries when it is done
+  alignas (8) int16_t lev_scratch[384];                  // sparse mode: the macroblock in hand, turned into list entries when it is done
   // a coded macroblock is done: note whether it has any nonzero level; in sparse mode list them (picture-relative index << 16 | value)
   void finish_levels (int k) {
     const int16_t* lv = self->sparse_levels_ ? lev_scratch : &cur->levels[(size_t)k * 384];
-    const uint64_t* q = (const uint64_t*)lv;
     bool any = false;
-    for (int i = 0; i < 96; i++) if (q[i]) {
-        any = true;
-        if (!self->sparse_levels_) break;
-        for (int j = 0; j < 4; j++) { const int16_t v = lv[4 * i + j]; if (v) cur->sparse.push_back (((uint64_t) ((size_t)k * 384 + 4 * i + j) << 16) | (uint16_t)v); }
-      }
+    for (int i = 0; i < 96; i++) {
+      uint64_t q;
+      memcpy (&q, lv + 4 * i, 8);
+      if (!q) continue;
+      any = true;
+      if (!self->sparse_levels_) break;
+      for (int j = 0; j < 4; j++) { const int16_t v = lv[4 * i + j]; if (v) cur->sparse.push_back (((uint64_t) ((size_t)k * 384 + 4 * i + j) << 16) | (uint16_t)v); }
+    }
     cur->lev_nonzero[k] = any ? 1 : 0;
   }       // the slice NAL just handled: header length in bits, entropy mode
 

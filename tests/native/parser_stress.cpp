@@ -12,8 +12,22 @@
 static uint32_t rng_state = 12345;
 static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
 
+// chunk 2: the configuration of the batch compressor (whole file at once, pictures in a stream arena, levels as a sparse list,
+// no dequantised coefficients)
 static long run (const std::vector<uint8_t>& bs, size_t chunk) {
   lh264host::Parser p;
+  if (chunk == 2) {
+    p.set_stream_arena (true); p.set_sparse_levels (true); p.set_want_coeffs (false);
+    p.feed_file (bs.data(), bs.size());
+    long mbs = 0;
+    for (auto& f : p.frames()) {
+      mbs += (long)f->mbs.size();
+      if (f->levels.size() != 0 || f->coeffs.size() != 0) { fprintf (stderr, "planes allocated in sparse mode\n"); exit (3); }
+      for (uint64_t e : f->sparse) if ((e >> 16) >= (uint64_t)f->mbs.size() * 384 || (e & 0xffff) == 0) { fprintf (stderr, "bad sparse entry\n"); exit (3); }
+      if (f->syn_off.size() && f->syn_off.back() != f->syn_syms.size()) { fprintf (stderr, "symbol offsets inconsistent\n"); exit (3); }
+    }
+    return mbs;
+  }
   if (chunk == 0) p.feed (bs.data(), bs.size());
   else {
     // split at start codes, like the console decoder
@@ -44,16 +58,16 @@ int main (int argc, char** argv) {
     std::vector<uint8_t> bs; uint8_t tmp[65536]; size_t n;
     while ((n = fread (tmp, 1, sizeof (tmp), f)) > 0) bs.insert (bs.end(), tmp, tmp + n);
     fclose (f);
-    total += run (bs, 0); total += run (bs, 1); cases += 2;
+    total += run (bs, 0); total += run (bs, 1); total += run (bs, 2); cases += 3;
     for (int t = 0; t < 24; t++) {                 // truncations
       std::vector<uint8_t> c (bs.begin(), bs.begin() + (size_t) (rnd() % (bs.size() + 1)));
-      total += run (c, t & 1); cases++;
+      total += run (c, t % 3); cases++;
     }
     for (int t = 0; t < 40; t++) {                 // corruptions: a few random bytes overwritten
       std::vector<uint8_t> c = bs;
       const int k = 1 + (int) (rnd() % 8);
       for (int i = 0; i < k; i++) c[rnd() % c.size()] = (uint8_t)rnd();
-      total += run (c, t & 1); cases++;
+      total += run (c, t % 3); cases++;
     }
     {                                              // empty and tiny inputs
       std::vector<uint8_t> e; total += run (e, 0);
