@@ -121,11 +121,13 @@ struct WalkState { int left_nz, prev, prev2, emitted; };
 
 // encode4x4's coefficient loop (decode_slice.cpp:2059-2094) over scan positions [16*CH, 16*CH+16): every coefficient
 // up to the last nonzero one is a symbol whose prior depends on the two previous levels and the nonzeros left
+// wmax: the largest `last` of the wave (uniform): positions beyond it are skipped four at a time without being looked at
 template <int CH>
-__device__ __forceinline__ void walk16 (const int c[16], int start, int last, uint32_t outer0, int kind, WalkState& w, LDS uint64_t* dst) {
+__device__ __forceinline__ void walk16 (const int c[16], int start, int last, int wmax, uint32_t outer0, int kind, WalkState& w, LDS uint64_t* dst) {
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     const int pos = CH * 16 + i;
+    if ((i & 3) == 0 && wmax < pos) return;
     if (pos >= start && pos <= last) {
       const uint32_t inner = (uint32_t) ((((min (4, w.left_nz) * 5 + clamp04 (w.prev + 2)) * 5 + clamp04 (w.prev2 + 2)) * 5 + 2) * 5 + 2);
       dst[w.emitted] = mk_sym ((outer0 + w.emitted) * 3125u + inner, c[i], kind);
@@ -224,6 +226,9 @@ ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int bl
   for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up (incl, d); if (lane >= d) incl += t; }
   const int total = __shfl (incl, 23) + ndc_l + ndc_c;
   const int my_off = ndc_l + ndc_c + incl - cnt;
+  int wmax = coded ? last : -1;                     // largest scan position any block of the macroblock reaches
+  for (int d = 32; d; d >>= 1) wmax = max (wmax, __shfl_xor (wmax, d));
+  wmax = __builtin_amdgcn_readfirstlane (wmax);
   if (coded) {
     const int color = luma ? 0 : (b < 20 ? 1 : 2);
     LDS const uint8_t* C = W.nz[0], *Lf = W.nz[1], *Ab = W.nz[2], *Pa = W.nz[3];
@@ -250,12 +255,12 @@ ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int bl
                      big ? LH264_SYM_NZ8 : LH264_SYM_NZ4);
     const uint32_t outer0 = (uint32_t) (((st * 16 + mbc) * 3 + color) * nco);
     WalkState w = {nonzeros, 0, 0, 0};
-    if (!big) walk16<0> (c, start, last, outer0, LH264_SYM_AC4, w, dst + 1);
+    if (!big) walk16<0> (c, start, last, wmax, outer0, LH264_SYM_AC4, w, dst + 1);
     else {
-      load_scan16<64, 0> (ac, c); walk16<0> (c, start, last, outer0, LH264_SYM_AC8, w, dst + 1);
-      load_scan16<64, 1> (ac, c); walk16<1> (c, start, last, outer0, LH264_SYM_AC8, w, dst + 1);
-      load_scan16<64, 2> (ac, c); walk16<2> (c, start, last, outer0, LH264_SYM_AC8, w, dst + 1);
-      load_scan16<64, 3> (ac, c); walk16<3> (c, start, last, outer0, LH264_SYM_AC8, w, dst + 1);
+      load_scan16<64, 0> (ac, c); walk16<0> (c, start, last, wmax, outer0, LH264_SYM_AC8, w, dst + 1);
+      load_scan16<64, 1> (ac, c); walk16<1> (c, start, last, wmax, outer0, LH264_SYM_AC8, w, dst + 1);
+      load_scan16<64, 2> (ac, c); walk16<2> (c, start, last, wmax, outer0, LH264_SYM_AC8, w, dst + 1);
+      load_scan16<64, 3> (ac, c); walk16<3> (c, start, last, wmax, outer0, LH264_SYM_AC8, w, dst + 1);
     }
   }
   if (lane >= 32 && lane < 48) {
