@@ -244,7 +244,9 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
   // Streams are parsed in waves on the host threads; parsed streams collect into a group until the group is worth a launch
   // (bounded by macroblock count: the symbol buffer takes 3.4 KB per macroblock); the group's staging, upload, kernels and
   // download run on their own host thread while the next wave is being parsed.
-  size_t kBudget = 5200000;                       // upper bound; lowered below to a third of the projected work so that groups overlap
+  // one launch of the coder takes ~0.12 s however few streams it codes, and a group of this size takes about as long to parse
+  // as its device stage lasts: smaller groups only add launches
+  const size_t kBudget = 5200000;
   const int kWave = std::max (8, 4 * threads);
   // device and page-locked buffers live across calls (allocating and releasing ~20 GB costs more than a whole batch):
   // one arena per process, one compress call at a time; lh264_compress_release() gives the memory back
@@ -281,12 +283,6 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
       if (data[i] || !len[i]) parsers[i]->feed_file (data[i], len[i]);
     });
     if (trace_on()) fprintf (stderr, "[lh264 compress] wave of %d streams parsed in %.3f s\n", w1 - w0, now_s() - t_p);
-    if (w0 == 0) {                                 // project the whole batch from its first wave: macroblocks per input byte
-      size_t mb = 0, by = 0, all = 0;
-      for (int i = w0; i < w1; i++) { by += len[i]; for (auto& f : parsers[i]->frames()) mb += (size_t)f->mb_w * f->mb_h; }
-      for (int i = 0; i < n; i++) all += len[i];
-      if (by) { const double proj = (double)mb / (double)by * (double)all; kBudget = (size_t)std::min (5200000.0, std::max (1300000.0, proj / 3.0)); }
-    }
     for (int i = w0; i < w1; i++) {
       lh264_compressed_t& r = *out[i];
       lh264host::Parser& P = *parsers[i];
