@@ -338,6 +338,10 @@ int lh264_pip_restore_file (const uint8_t* file, size_t len, uint8_t* out, size_
  * does not parse; LH264_E_HIP ...), lh264_compressed_error gives the text. */
 typedef struct lh264_compressed lh264_compressed_t;
 int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, int threads, lh264_compressed_t** out);
+/* the same over several devices of one node: contiguous shares of about equal input size, one host thread per device driving
+ * lh264_compress_batch there (the streams are independent: nothing is exchanged between devices) */
+int lh264_compress_batch_devices (const uint8_t* const* data, const size_t* len, int n, int threads, const int* devices, int n_devices,
+                                  lh264_compressed_t** out);
 int lh264_compressed_status (const lh264_compressed_t* c);
 const char* lh264_compressed_error (const lh264_compressed_t* c);
 const uint8_t* lh264_compressed_main (const lh264_compressed_t* c, size_t* len);

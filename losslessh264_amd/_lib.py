@@ -66,6 +66,7 @@ _SIGS.update({
     "lh264_pip_restore": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lh264_restore_error": (C.c_char_p, []),
     "lh264_compress_batch": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "lh264_compress_batch_devices": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "lh264_compressed_status": (C.c_int, [C.c_void_p]),
     "lh264_compressed_error": (C.c_char_p, [C.c_void_p]),
     "lh264_compressed_main": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),

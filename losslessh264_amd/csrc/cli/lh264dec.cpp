@@ -146,7 +146,12 @@ static int compress_single (const std::vector<std::string>& srcs, const std::vec
   std::vector<const uint8_t*> d (n); std::vector<size_t> l (n);
   for (int i = 0; i < n; i++) { if (!load (srcs[i], in[i])) { perror (srcs[i].c_str()); return 2; } d[i] = in[i].data(); l[i] = in[i].size(); }
   std::vector<lh264_compressed_t*> h (n, nullptr);
-  const int rc = lh264_compress_batch (d.data(), l.data(), n, 0, h.data());
+  // every device of the node takes a share of the batch
+  const int nd = lh264_device_count();
+  std::vector<int> devs;
+  for (int i = 0; i < nd && i < n; i++) devs.push_back (i);
+  const int rc = devs.size() > 1 ? lh264_compress_batch_devices (d.data(), l.data(), n, 0, devs.data(), (int)devs.size(), h.data())
+                                 : lh264_compress_batch (d.data(), l.data(), n, 0, h.data());
   int ret = 0;
   for (int i = 0; i < n; i++) {
     Bytes blob; std::string why;

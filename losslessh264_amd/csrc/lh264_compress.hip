@@ -226,8 +226,9 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
                            t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, now_s() - t_e);
 }
 
-std::unique_ptr<Arena> g_arena;
-int g_arena_device = -1;
+enum { kMaxDevices = 16 };
+std::unique_ptr<Arena> g_arena[kMaxDevices];      // one per device: device and page-locked buffers kept between calls
+std::mutex g_arena_mutex[kMaxDevices];             // one compress call at a time per device
 
 }  // namespace
 
@@ -250,10 +251,10 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
   const int kWave = std::max (8, 4 * threads);
   // device and page-locked buffers live across calls (allocating and releasing ~20 GB costs more than a whole batch):
   // one arena per process, one compress call at a time; lh264_compress_release() gives the memory back
-  static std::mutex arena_mutex;
-  std::lock_guard<std::mutex> arena_lock (arena_mutex);
-  if (!g_arena || g_arena_device != device) { g_arena.reset (new Arena()); g_arena_device = device; }
-  Arena& arena = *g_arena;
+  if (device < 0 || device >= kMaxDevices) return LH264_E_ARG;
+  std::lock_guard<std::mutex> arena_lock (g_arena_mutex[device]);
+  if (!g_arena[device]) g_arena[device].reset (new Arena());
+  Arena& arena = *g_arena[device];
   const double t_call = now_s();
   std::vector<std::unique_ptr<lh264host::Parser>> parsers (n);
   std::thread device_thread;
@@ -303,7 +304,46 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
   if (trace_on()) fprintf (stderr, "[lh264 compress] %d streams: %.3f s\n", n, now_s() - t_call);
   return LH264_OK;
 }
-void lh264_compress_release (void) { g_arena.reset(); }
+void lh264_compress_release (void) {
+  int cur = 0;
+  hipGetDevice (&cur);
+  for (int d = 0; d < kMaxDevices; d++) {
+    std::lock_guard<std::mutex> lock (g_arena_mutex[d]);
+    if (g_arena[d]) { hipSetDevice (d); g_arena[d].reset(); }
+  }
+  hipSetDevice (cur);
+}
+
+// the same batch over several devices of the node: the streams are cut into contiguous shares of about equal input size, one
+// host thread per share drives lh264_compress_batch on its device (streams are independent: no exchange between devices)
+int lh264_compress_batch_devices (const uint8_t* const* data, const size_t* len, int n, int threads, const int* devices, int n_devices,
+                                  lh264_compressed_t** out) {
+  if (!data || !len || !out || n < 0 || !devices || n_devices < 1) return LH264_E_ARG;
+  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+  size_t total = 0;
+  for (int i = 0; i < n; i++) total += len[i];
+  std::vector<int> first (n_devices + 1, n);
+  first[0] = 0;
+  {
+    size_t acc = 0; int s = 1;
+    for (int i = 0; i < n && s < n_devices; i++) {
+      acc += len[i];
+      while (s < n_devices && acc * n_devices >= total * s) first[s++] = i + 1;
+    }
+  }
+  std::vector<int> rcs (n_devices, LH264_OK);
+  std::vector<std::thread> th;
+  for (int s = 0; s < n_devices; s++) {
+    th.emplace_back ([&, s] () {
+      const int a = first[s], b = first[s + 1];
+      if (hipSetDevice (devices[s]) != hipSuccess) { for (int i = a; i < b; i++) { out[i] = new lh264_compressed(); out[i]->status = LH264_E_HIP; out[i]->error = "hipSetDevice failed"; } rcs[s] = LH264_E_HIP; return; }
+      rcs[s] = lh264_compress_batch (data + a, len + a, b - a, std::max (1, threads / n_devices), out + a);
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int rc : rcs) if (rc != LH264_OK) return rc;
+  return LH264_OK;
+}
 int lh264_compressed_status (const lh264_compressed_t* c) { return c ? c->status : LH264_E_ARG; }
 const char* lh264_compressed_error (const lh264_compressed_t* c) { return c ? c->error.c_str() : ""; }
 const uint8_t* lh264_compressed_main (const lh264_compressed_t* c, size_t* len) {

@@ -103,15 +103,20 @@ def restore_file(blob, size_hint=None):
     raise RuntimeError("restore failed: " + lib.lh264_restore_error().decode())
 
 
-def compress_batch(datas, threads=0):
+def compress_batch(datas, threads=0, devices=None):
     """the whole compress direction behind one C call (lh264_compress_batch): list of Annex-B byte strings ->
-    list of (main bytes, {tag: bytes}, error text or None)"""
+    list of (main bytes, {tag: bytes}, error text or None).  devices: list of device indices to shard the batch over
+    (lh264_compress_batch_devices); default: the current device"""
     lib = L.lib()
     n = len(datas)
     ptrs = (C.c_char_p * n)(*[bytes(d) for d in datas])
     lens = (C.c_size_t * n)(*[len(d) for d in datas])
     outs = (C.c_void_p * n)()
-    L.check(lib.lh264_compress_batch(ptrs, lens, n, threads, outs))
+    if devices:
+        devs = (C.c_int * len(devices))(*devices)
+        L.check(lib.lh264_compress_batch_devices(ptrs, lens, n, threads, devs, len(devices), outs))
+    else:
+        L.check(lib.lh264_compress_batch(ptrs, lens, n, threads, outs))
     res = []
     for i in range(n):
         h = outs[i]

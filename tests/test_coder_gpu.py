@@ -144,6 +144,22 @@ def test_compress_batch_c_api_equals_reference_cli():
         assert lh.restore(main, tags) == data, name
 
 
+def test_compress_batch_over_devices_equals_single_device():
+    """lh264_compress_batch_devices: the batch cut into contiguous shares, one host thread per share; with every device of the box
+    (on a one-GPU box: two shares on device 0, which exercises the share arithmetic and the per-device arena lock) the result is the
+    single-call result, share boundaries included (more shares than streams, empty shares)"""
+    import torch
+    import losslessh264_amd as lh
+    datas = [open(os.path.join(golden_io.GOLDEN_DIR, "streams", n), "rb").read() for n in CLI]
+    one = lh.compress_batch(datas, 8)
+    nd = torch.cuda.device_count()
+    devs = list(range(nd)) if nd > 1 else [0, 0]
+    assert lh.compress_batch(datas, 8, devices=devs) == one
+    assert lh.compress_batch(datas, 8, devices=[0, 0, 0]) == one
+    assert lh.compress_batch(datas[:2], 8, devices=[0] * 5) == one[:2]
+    assert lh.compress_batch([], 8, devices=[0, 0]) == []
+
+
 def test_cpp_console_application(tmp_path):
     """losslessh264_amd/lh264dec (C++, built by __graft_entry__.build against include/*.h): the reference console application's
     calling convention and files, the YUV dump, the single-file mode with its verbatim fallback, and the batch mode"""
