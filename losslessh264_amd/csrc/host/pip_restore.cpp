@@ -38,7 +38,7 @@ struct DynProb {
 // ---- the bool decoder (libvpx dboolhuff as vendored by the reference: bitreader.h:77-136, bitreader.cpp:43-108) -----------
 struct BoolReader {
   const uint8_t* p = nullptr; const uint8_t* end = nullptr;
-  uint64_t value = 0; int count = -8; uint32_t range = 255; bool present = false, started = false;
+  uint64_t value = 0; int count = -8; uint32_t range = 255; bool present = false;
   void fill() {
     int shift = 64 - 8 - (count + 8);
     while (shift >= 0) {
@@ -47,7 +47,6 @@ struct BoolReader {
     }
   }
   inline int read (int prob) {
-    if (!started) { started = true; value = 0; count = -8; range = 255; fill(); }
     const uint32_t split = 1 + (((range - 1) * (uint32_t)prob) >> 8);
     if (count < 0) fill();
     const uint64_t bigsplit = (uint64_t)split << 56;
@@ -67,30 +66,32 @@ const int kTreeBits[LH264_TB_COUNT] = {4, 0, 3, 0, 0, 0, 0, 0, 0, 9, 7, 8, 4, 2,
 
 class PriorStore {
  public:
-  PriorStore() { keys_.assign (1u << 16, 0); offs_.assign (1u << 16, 0); }
+  PriorStore() { slots_.assign (1u << 16, Slot{0, 0}); }
   DynProb* get (int table, uint32_t index) {          // valid until the next get
     const uint32_t key = LH264_PRIOR (table, index) + 1u;
-    if (used_ * 2 >= keys_.size()) grow();
-    size_t h = hash (key) & (keys_.size() - 1);
-    while (keys_[h] && keys_[h] != key) h = (h + 1) & (keys_.size() - 1);
-    if (!keys_[h]) {
-      keys_[h] = key; offs_[h] = (uint32_t)pool_.size(); used_++;
+    if (used_ * 2 >= slots_.size()) grow();
+    const size_t mask = slots_.size() - 1;
+    size_t h = hash (key) & mask;
+    while (slots_[h].key && slots_[h].key != key) h = (h + 1) & mask;
+    if (!slots_[h].key) {
+      slots_[h].key = key; slots_[h].off = (uint32_t)pool_.size(); used_++;
       pool_.resize (pool_.size() + (size_t)kCell[table]);
     }
-    return pool_.data() + offs_[h];
+    return pool_.data() + slots_[h].off;
   }
  private:
+  struct Slot { uint32_t key, off; };                  // key and offset side by side: one cache line per probe
   static inline uint32_t hash (uint32_t k) { return (uint32_t) ((k * 0x9E3779B97F4A7C15ull) >> 32); }
   void grow() {
-    std::vector<uint32_t> k2 (keys_.size() * 2, 0), o2 (keys_.size() * 2, 0);
-    for (size_t i = 0; i < keys_.size(); i++) if (keys_[i]) {
-        size_t h = hash (keys_[i]) & (k2.size() - 1);
-        while (k2[h]) h = (h + 1) & (k2.size() - 1);
-        k2[h] = keys_[i]; o2[h] = offs_[i];
+    std::vector<Slot> s2 (slots_.size() * 2, Slot{0, 0});
+    for (const Slot& s : slots_) if (s.key) {
+        size_t h = hash (s.key) & (s2.size() - 1);
+        while (s2[h].key) h = (h + 1) & (s2.size() - 1);
+        s2[h] = s;
       }
-    keys_.swap (k2); offs_.swap (o2);
+    slots_.swap (s2);
   }
-  std::vector<uint32_t> keys_, offs_;
+  std::vector<Slot> slots_;
   std::vector<DynProb> pool_;
   size_t used_ = 0;
 };
@@ -205,7 +206,7 @@ struct MbDec {                        // one decoded macroblock
 class Restorer {
  public:
   Restorer (const uint8_t* const* tags, const size_t* tag_len, int n_tags, std::string& err) : err_ (err) {
-    for (int t = 0; t < N_TAGS && t < n_tags; t++) if (tags[t]) { rd_[t].p = tags[t]; rd_[t].end = tags[t] + tag_len[t]; rd_[t].present = true; }
+    for (int t = 0; t < N_TAGS && t < n_tags; t++) if (tags[t]) { rd_[t].p = tags[t]; rd_[t].end = tags[t] + tag_len[t]; rd_[t].present = true; rd_[t].fill(); }
     build_vlc();
   }
   int run (const uint8_t* d, size_t n, std::vector<uint8_t>& out);
@@ -347,7 +348,8 @@ void Restorer::decode_coeffs (MbDec& m, int st, int mbc, const Cell* nl, const C
   };
   if (i16) for (int i = 0; i < 16; i++) lev[i * 16] = (int16_t)dc (LH264_TB_LDC, i, TAG_LDC);
   if (cdc) for (int i = 0; i < 8; i++) lev[256 + i * 16] = (int16_t)dc (LH264_TB_CDC, i, TAG_CRDC);
-  auto count16 = [&] (int blk) { int c = 0; for (int i = 0; i < 16; i++) c += lev[blk * 16 + i] != 0; return (uint8_t)c; };
+  // e.nnz[b] = the nonzero levels of 4x4 block b (a separately coded DC included), counted as they are decoded
+  for (int b = 0; b < 24; b++) C[b] = (uint8_t) (lev[b * 16] != 0);
   for (int b = 0; b < 24; b++) {
     const bool luma = b < 16;
     const bool big = luma && m.t8;
@@ -391,13 +393,12 @@ void Restorer::decode_coeffs (MbDec& m, int st, int mbc, const Cell* nl, const C
         const int v = scan_uegk (store_.get (big ? LH264_TB_AC8 : LH264_TB_AC4, (outer0 + (uint32_t)emitted) * 3125u + inner), 14, 4, 2, 4, 0,
                                  base + 2, base + 3, base + 1, base + 4);
         if (v < -32768 || v > 32767) { fail ("corrupt coefficient"); return; }
-        lev[b * 16 + (big ? kZz64[pos] : kZz16[pos])] = (int16_t)v;
+        const int at = big ? kZz64[pos] : kZz16[pos];
+        lev[b * 16 + at] = (int16_t)v;
         prev2 = prev; prev = v; emitted++;
-        if (v) left_nz--;
+        if (v) { left_nz--; C[b + (at >> 4)]++; }
       }
     }
-    if (big) { if ((b & 3) == 0) for (int j = 0; j < 4; j++) C[b + j] = count16 (b + j); }
-    else C[b] = count16 (b);
   }
 }
 
