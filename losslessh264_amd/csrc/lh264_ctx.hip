@@ -43,13 +43,16 @@ ctx_nnz_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int blocks
   const int n = J->mb_w * J->mb_h;
   const int k = (blockIdx.x % blocks_per_job) * 4 + wave;
   if (k >= n) return;
-  const int type = __builtin_amdgcn_readfirstlane ((int)as_glb<const lh264_mb_t> (J->mbs_dev)[k].mb_type);
-  if (type == LH264_MB_SKIP || type == 0) return;       // inherited from PAST by pass 1b
+  // the macroblock type and the levels are requested together (one memory round trip, not two)
   const GLB int16_t* lv = as_glb<const int16_t> (J->levels_dev) + (size_t)k * 384;
   GLB uint8_t* cur = as_glb<uint8_t> (J->nnz_cur_dev) + (size_t)k * 24;
+  const int type_l = as_glb<const lh264_mb_t> (J->mbs_dev)[k].mb_type;
   const v2i a = * (const GLB v2i*) (lv + 4 * lane);
   v2i b = {0, 0};
   if (lane < 32) b = * (const GLB v2i*) (lv + 256 + 4 * lane);
+  asm volatile ("" : : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));      // keeps the loads above the branch
+  const int type = __builtin_amdgcn_readfirstlane (type_l);
+  if (type == LH264_MB_SKIP || type == 0) return;       // inherited from PAST by pass 1b
   int c = ((a.x & 0xffff) != 0) + ((a.x >> 16) != 0) + ((a.y & 0xffff) != 0) + ((a.y >> 16) != 0);
   c += __shfl_xor (c, 1); c += __shfl_xor (c, 2);       // luma block = lane >> 2
   int d = ((b.x & 0xffff) != 0) + ((b.x >> 16) != 0) + ((b.y & 0xffff) != 0) + ((b.y >> 16) != 0);
@@ -161,30 +164,37 @@ ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int bl
   GLB uint64_t* out = (GLB uint64_t*) (as_glb<lh264_ctx_sym_t> (J->syms_dev) + (size_t)k * LH264_CTX_MAX_SYMS);
   GLB uint16_t* nout = as_glb<uint16_t> (J->n_syms_dev) + k;
 
-  const uint32_t head = __builtin_amdgcn_readfirstlane ((int) * (const GLB uint32_t*)m);      // mb_type | cbp << 16 | qp << 24
+  // Every global read of the macroblock is issued before anything is looked at: the record (lanes 0..7 take a dword each),
+  // the levels and the four nnz entries travel together, one memory round trip instead of a chain of three (a wave has
+  // nothing else to hide them behind; for a skipped macroblock the levels are read for nothing)
+  const int mbx = k % mb_w;
+  const uint32_t rec = lane < 8 ? ((const GLB uint32_t*)m)[lane] : 0u;
+  const v2i l0 = * (const GLB v2i*) (lv + 4 * lane);
+  v2i l1 = {0, 0};
+  if (lane < 32) l1 = * (const GLB v2i*) (lv + 256 + 4 * lane);
+  const int who = lane / 6, q = lane % 6;
+  uint32_t nzv = 0;
+  if (lane < 24) {
+    if (who == 0) nzv = ((const GLB uint32_t*) (cur + (size_t)k * 24))[q];
+    else if (who == 1) { if (mbx > 0) nzv = ((const GLB uint32_t*) (cur + (size_t) (k - 1) * 24))[q]; }
+    else if (who == 2) { if (k >= mb_w) nzv = ((const GLB uint32_t*) (cur + (size_t) (k - mb_w) * 24))[q]; }
+    else if (J->nnz_past_dev) nzv = ((const GLB uint32_t*) (as_glb<const uint8_t> (J->nnz_past_dev) + (size_t)k * 24))[q];
+  }
+  // stage levels and the four nnz entries
+  * (LDS v2i*) (W.lv + 4 * lane) = l0;
+  if (lane < 32) * (LDS v2i*) (W.lv + 256 + 4 * lane) = l1;
+  if (lane < 24) ((LDS uint32_t*)W.nz[who])[q] = nzv;
+  const uint32_t head = (uint32_t)__builtin_amdgcn_readlane ((int)rec, 0);      // mb_type | cbp << 16 | qp << 24
   const int type = head & 0xffff;
   if (type == LH264_MB_SKIP || type == LH264_MB_IPCM || type == 0) {     // no coefficient symbols (writeBlock false / PCM)
     if (lane == 0) *nout = 0;
     return;
   }
   const int cbp = (head >> 16) & 0xff;
-  const int t8 = __builtin_amdgcn_readfirstlane ((int)m->flags) & LH264_MBF_T8x8;
-  const int sid = __builtin_amdgcn_readfirstlane ((int)m->slice_id);
+  const int t8 = (__builtin_amdgcn_readlane ((int)rec, 1) >> 16) & LH264_MBF_T8x8;                 // flags: byte 6
+  const int sid = (int) ((uint32_t)__builtin_amdgcn_readlane ((int)rec, 6) >> 16);                // slice_id: bytes 26..27
   const int st = as_glb<const lh264_slice_t> (J->slices_dev)[sid].slice_type;
   const int mbc = mb_type_code (type);
-  const int mbx = k % mb_w;
-  // stage levels and the four nnz entries
-  * (LDS v2i*) (W.lv + 4 * lane) = * (const GLB v2i*) (lv + 4 * lane);
-  if (lane < 32) * (LDS v2i*) (W.lv + 256 + 4 * lane) = * (const GLB v2i*) (lv + 256 + 4 * lane);
-  if (lane < 24) {
-    const int who = lane / 6, q = lane % 6;
-    uint32_t v = 0;
-    if (who == 0) v = ((const GLB uint32_t*) (cur + (size_t)k * 24))[q];
-    else if (who == 1) { if (mbx > 0) v = ((const GLB uint32_t*) (cur + (size_t) (k - 1) * 24))[q]; }
-    else if (who == 2) { if (k >= mb_w) v = ((const GLB uint32_t*) (cur + (size_t) (k - mb_w) * 24))[q]; }
-    else if (J->nnz_past_dev) v = ((const GLB uint32_t*) (as_glb<const uint8_t> (J->nnz_past_dev) + (size_t)k * 24))[q];
-    ((LDS uint32_t*)W.nz[who])[q] = v;
-  }
   asm volatile ("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 
