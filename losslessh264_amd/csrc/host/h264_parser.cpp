@@ -3,6 +3,8 @@
 // group -- the subset the reference decoder itself supports.
 #include "h264_parser.h"
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <atomic>
 #include <thread>
 #include <functional>
@@ -65,7 +67,9 @@ void* zerobuf_get (size_t bytes, bool zero) {
   for (int i = c.n - 1; i >= 0; i--) if (c.e[i].bytes == bytes) { p = c.e[i].p; c.e[i] = c.e[--c.n]; break; }
   if (!p && bytes >= 4096) p = shared_pool().get (bytes);
   if (p) { if (zero) memset (p, 0, bytes); return p; }
-  return zero ? calloc (1, bytes) : malloc (bytes);
+  p = zero ? calloc (1, bytes) : malloc (bytes);
+  if (!p) throw std::bad_alloc();            // caught at the parser's entry points (feed_nal / flush), never crosses the C ABI
+  return p;
 }
 void zerobuf_put (void* p, size_t bytes) {
   ZeroCache& c = g_zero_cache;
@@ -261,35 +265,57 @@ struct Parser::Impl {
   void parse_sps (BitReader& br) {
     Sps s;
     s.profile_idc = br.u (8); br.u (8); s.level_idc = br.u (8);
-    int id = br.ue();
+    const uint32_t id = br.ue();
+    if (id > 31) { fail ("seq_parameter_set_id out of range"); return; }
     memset (s.sl4, 16, sizeof (s.sl4)); memset (s.sl8, 16, sizeof (s.sl8));
     if (s.profile_idc == 100 || s.profile_idc == 110 || s.profile_idc == 122 || s.profile_idc == 244 || s.profile_idc == 44 ||
         s.profile_idc == 83 || s.profile_idc == 86 || s.profile_idc == 118 || s.profile_idc == 128) {
-      s.chroma_format_idc = br.ue();
+      const uint32_t cfi = br.ue();
+      if (cfi > 3) { fail ("chroma_format_idc out of range"); return; }
+      s.chroma_format_idc = (int)cfi;
       if (s.chroma_format_idc == 3) br.u1();
-      int bdl = br.ue(), bdc = br.ue();
+      const uint32_t bdl = br.ue(), bdc = br.ue();
       br.u1();
       if (s.chroma_format_idc != 1 || bdl || bdc) { self->n_unsupported_++; fail ("unsupported chroma format / bit depth"); return; }
       s.scaling_matrix_present = br.u1();
       if (s.scaling_matrix_present) parse_scaling_matrix (br, s.sl4, s.sl8, 8, nullptr);
     }
-    s.log2_max_frame_num = br.ue() + 4;
-    s.poc_type = br.ue();
-    if (s.poc_type == 0) s.log2_max_poc_lsb = br.ue() + 4;
-    else if (s.poc_type == 1) {
+    // every Exp-Golomb value is range-checked as unsigned BEFORE it is narrowed (H.264 7.4.2.1.1 limits)
+    const uint32_t l2fn = br.ue();
+    if (l2fn > 12) { fail ("log2_max_frame_num out of range"); return; }
+    s.log2_max_frame_num = (int)l2fn + 4;
+    const uint32_t pt = br.ue();
+    if (pt > 2) { fail ("pic_order_cnt_type out of range"); return; }
+    s.poc_type = (int)pt;
+    if (s.poc_type == 0) {
+      const uint32_t l2p = br.ue();
+      if (l2p > 12) { fail ("log2_max_pic_order_cnt_lsb out of range"); return; }
+      s.log2_max_poc_lsb = (int)l2p + 4;
+    } else if (s.poc_type == 1) {
       s.delta_pic_order_always_zero = br.u1();
       s.offset_for_non_ref_pic = br.se(); s.offset_for_top_to_bottom = br.se();
-      s.num_ref_frames_in_poc_cycle = br.ue();
-      for (int i = 0; i < s.num_ref_frames_in_poc_cycle && i < 256; i++) s.offset_for_ref_frame.push_back (br.se());
+      const uint32_t nc = br.ue();
+      if (nc > 255) { fail ("num_ref_frames_in_pic_order_cnt_cycle out of range"); return; }
+      s.num_ref_frames_in_poc_cycle = (int)nc;
+      for (int i = 0; i < s.num_ref_frames_in_poc_cycle; i++) s.offset_for_ref_frame.push_back (br.se());
     }
-    s.num_ref_frames = br.ue();
+    const uint32_t nrf = br.ue();
+    if (nrf > 16) { fail ("max_num_ref_frames out of range"); return; }
+    s.num_ref_frames = (int)nrf;
     s.gaps_allowed = br.u1();
-    s.mb_w = br.ue() + 1;
-    s.mb_h = br.ue() + 1;
+    const uint32_t mbw = br.ue(), mbh = br.ue();
+    // level 6.2 allows 139,264 macroblocks per frame and 16,384 samples per side (A.3.1): nothing larger is a picture
+    if (mbw >= 1024 || mbh >= 1024 || (uint64_t) (mbw + 1) * (mbh + 1) > 139264u) { fail ("picture size out of range"); return; }
+    s.mb_w = (int)mbw + 1;
+    s.mb_h = (int)mbh + 1;
     s.frame_mbs_only = br.u1();
     if (!s.frame_mbs_only) { br.u1(); self->n_unsupported_++; fail ("interlaced coding is not supported"); return; }
     s.direct_8x8 = br.u1();
-    if (br.u1()) { s.crop_l = br.ue(); s.crop_r = br.ue(); s.crop_t = br.ue(); s.crop_b = br.ue(); }
+    if (br.u1()) {
+      const uint32_t cl = br.ue(), cr = br.ue(), ct = br.ue(), cb = br.ue();
+      if ((uint64_t)cl + cr >= (uint64_t)s.mb_w * 8 || (uint64_t)ct + cb >= (uint64_t)s.mb_h * 8) { fail ("frame cropping outside the picture"); return; }
+      s.crop_l = (int)cl; s.crop_r = (int)cr; s.crop_t = (int)ct; s.crop_b = (int)cb;
+    }
     if (br.err) { fail ("truncated SPS"); return; }
     s.valid = true;
     sps[id] = s;
@@ -297,13 +323,18 @@ struct Parser::Impl {
 
   void parse_pps (BitReader& br) {
     Pps p;
-    int id = br.ue();
-    p.sps_id = br.ue();
+    const uint32_t id = br.ue(), sid = br.ue();
+    if (id > 255 || sid > 31) { fail ("parameter set id out of range"); return; }
+    p.sps_id = (int)sid;
     p.cabac = br.u1();
     p.pic_order_present = br.u1();
-    p.num_slice_groups = br.ue() + 1;
+    const uint32_t nsg = br.ue();
+    if (nsg > 7) { fail ("num_slice_groups out of range"); return; }
+    p.num_slice_groups = (int)nsg + 1;
     if (p.num_slice_groups > 1) { self->n_unsupported_++; fail ("FMO (slice groups) is not supported"); return; }
-    p.num_ref_idx_l0 = br.ue() + 1; p.num_ref_idx_l1 = br.ue() + 1;
+    const uint32_t nr0 = br.ue(), nr1 = br.ue();
+    if (nr0 > 31 || nr1 > 31) { fail ("num_ref_idx_default_active out of range"); return; }
+    p.num_ref_idx_l0 = (int)nr0 + 1; p.num_ref_idx_l1 = (int)nr1 + 1;
     p.weighted_pred = br.u1(); p.weighted_bipred_idc = br.u (2);
     p.pic_init_qp = 26 + br.se(); p.pic_init_qs = 26 + br.se();
     p.chroma_qp_offset[0] = p.chroma_qp_offset[1] = br.se();
@@ -325,12 +356,18 @@ struct Parser::Impl {
 
   bool parse_slice_header (BitReader& br, int nal_type, int nal_ref_idc, SliceHeader& sh) {
     sh.idr = nal_type == 5; sh.nal_ref_idc = nal_ref_idc;
-    sh.first_mb = br.ue();
-    int st = br.ue();
+    const uint32_t fmb = br.ue();
+    if (fmb >= 139264u) { fail ("first_mb_in_slice out of range"); return false; }
+    sh.first_mb = (int)fmb;
+    const uint32_t stu = br.ue();
+    if (stu > 9) { fail ("slice_type out of range"); return false; }
+    int st = (int)stu;
     if (st >= 5) st -= 5;
     if (st != 0 && st != 2) { self->n_unsupported_++; fail ("only I and P slices are supported"); return false; }
     sh.slice_type = st;
-    sh.pps_id = br.ue();
+    const uint32_t pid = br.ue();
+    if (pid > 255) { fail ("pic_parameter_set_id out of range"); return false; }
+    sh.pps_id = (int)pid;
     auto pit = pps.find (sh.pps_id);
     if (pit == pps.end() || !pit->second.valid) { fail ("slice refers to a missing PPS"); return false; }
     const Pps& P = pit->second;
@@ -338,24 +375,34 @@ struct Parser::Impl {
     if (sit == sps.end() || !sit->second.valid) { fail ("slice refers to a missing SPS"); return false; }
     const Sps& S = sit->second;
     sh.frame_num = br.u (S.log2_max_frame_num);
-    if (sh.idr) sh.idr_pic_id = br.ue();
+    if (sh.idr) { const uint32_t v = br.ue(); if (v > 65535) { fail ("idr_pic_id out of range"); return false; } sh.idr_pic_id = (int)v; }
     if (S.poc_type == 0) { sh.poc_lsb = br.u (S.log2_max_poc_lsb); if (P.pic_order_present) sh.delta_poc_bottom = br.se(); }
     else if (S.poc_type == 1 && !S.delta_pic_order_always_zero) { sh.delta_poc[0] = br.se(); if (P.pic_order_present) sh.delta_poc[1] = br.se(); }
-    if (P.redundant_pic_cnt) sh.redundant_pic_cnt = br.ue();
+    if (P.redundant_pic_cnt) { const uint32_t v = br.ue(); if (v > 127) { fail ("redundant_pic_cnt out of range"); return false; } sh.redundant_pic_cnt = (int)v; }
     sh.num_ref_idx_l0 = P.num_ref_idx_l0;
     if (st == 0) {
-      if (br.u1()) sh.num_ref_idx_l0 = br.ue() + 1;
+      if (br.u1()) {
+        const uint32_t nr = br.ue();
+        if (nr > 31) { fail ("num_ref_idx_l0_active out of range"); return false; }
+        sh.num_ref_idx_l0 = (int)nr + 1;
+      }
       if (br.u1()) {            // ref_pic_list_modification_flag_l0
         for (;;) {
-          int idc = br.ue();
-          if (idc == 3 || br.err) break;
-          sh.reorder.push_back ({idc, br.ue()});
+          const uint32_t idcu = br.ue();
+          if (idcu == 3 || br.err) break;
+          if (idcu > 3) { fail ("bad ref list modification"); return false; }
+          const int idc = (int)idcu;
+          const uint32_t rv = br.ue();
+          if (rv > 0x7fffffffu) { fail ("bad ref list modification"); return false; }
+          sh.reorder.push_back ({idc, rv});
           if (sh.reorder.size() > 64) { fail ("bad ref list modification"); return false; }
         }
       }
       if (P.weighted_pred) {
         sh.has_weights = true;
-        sh.luma_log2_denom = br.ue(); sh.chroma_log2_denom = br.ue();
+        const uint32_t ld = br.ue(), cd = br.ue();
+        if (ld > 7 || cd > 7) { fail ("weight denominator out of range"); return false; }
+        sh.luma_log2_denom = (int)ld; sh.chroma_log2_denom = (int)cd;
         for (int i = 0; i < sh.num_ref_idx_l0 && i < 32; i++) {
           sh.luma_weight[i] = 1 << sh.luma_log2_denom; sh.luma_offset[i] = 0;
           for (int c = 0; c < 2; c++) { sh.chroma_weight[i][c] = 1 << sh.chroma_log2_denom; sh.chroma_offset[i][c] = 0; }
@@ -368,13 +415,16 @@ struct Parser::Impl {
       if (sh.idr) { sh.no_output_of_prior = br.u1(); sh.long_term_reference = br.u1(); }
       else if ((sh.adaptive_marking = br.u1())) {
         for (;;) {
-          int op = br.ue();
-          if (op == 0 || br.err) break;
+          const uint32_t opu = br.ue();
+          if (opu == 0 || br.err) break;
+          if (opu > 6) { fail ("bad mmco list"); return false; }
+          const int op = (int)opu;
           SliceHeader::Mmco m = {op, 0, 0};
-          if (op == 1 || op == 3) m.a = br.ue();
-          if (op == 2) m.a = br.ue();
-          if (op == 3 || op == 6) m.b = br.ue();
-          if (op == 4) m.a = br.ue();
+          auto small = [&] () -> int { const uint32_t v = br.ue(); if (v > 0x00ffffffu) br.err = true; return (int) (v & 0x00ffffffu); };
+          if (op == 1 || op == 3) m.a = small();
+          if (op == 2) m.a = small();
+          if (op == 3 || op == 6) m.b = small();
+          if (op == 4) m.a = small();
           sh.mmco.push_back (m);
           if (sh.mmco.size() > 66) { fail ("bad mmco list"); return false; }
         }
@@ -383,8 +433,14 @@ struct Parser::Impl {
     if (P.cabac && st != 2) { const uint32_t ci = br.ue(); sh.cabac_init_idc = (int) (ci & 3); if (ci > 2) { fail ("cabac_init_idc out of range"); return false; } }
     sh.slice_qp = P.pic_init_qp + br.se();
     if (P.deblocking_control) {
-      sh.deblock_idc = br.ue();
-      if (sh.deblock_idc != 1) { sh.alpha_off = br.se() * 2; sh.beta_off = br.se() * 2; }
+      const uint32_t di = br.ue();
+      if (di > 2) { fail ("disable_deblocking_filter_idc out of range"); return false; }
+      sh.deblock_idc = (int)di;
+      if (sh.deblock_idc != 1) {
+        const int ao = br.se(), bo = br.se();
+        if (ao < -6 || ao > 6 || bo < -6 || bo > 6) { fail ("deblocking offsets out of range"); return false; }
+        sh.alpha_off = ao * 2; sh.beta_off = bo * 2;
+      }
     }
     return !br.err;
   }
@@ -776,6 +832,7 @@ void Parser::Impl::finalize_intra_modes (SliceCtx& c, int k, const int* raw, boo
 bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_prev, bool is_skip) {
   const Sps& S = *c.S; const Pps& P = *c.P; const SliceHeader& sh = *c.sh;
   const int sid = c.sid, w = cur->mb_w;
+  if (k < 0 || k >= cur->mb_w * cur->mb_h) { fail ("macroblock address out of range"); return false; }
   lh264_mb_t& m = cur->mbs[k];
   MbState& s = st[k];
   memset (&m, 0, sizeof (m));
@@ -880,14 +937,14 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
       have_raw = true;
       chroma_mode = (int)br.ue();
       const uint32_t ci = br.ue();
-      if (ci > 47 || chroma_mode > 3) { fail ("invalid cbp / chroma mode"); return false; }
+      if (ci > 47 || chroma_mode < 0 || chroma_mode > 3) { fail ("invalid cbp / chroma mode"); return false; }
       cbp = kCbpIntra[ci];
     } else {                                            // Intra16x16
       m.mb_type = LH264_MB_I16x16; s.type_class = 2;
       i16mode = (mbt - 1) & 3;
       cbp = (((mbt - 1) >> 2) % 3) << 4 | ((mbt - 1) >= 12 ? 15 : 0);
       chroma_mode = (int)br.ue();
-      if (chroma_mode > 3) { fail ("invalid chroma mode"); return false; }
+      if (chroma_mode < 0 || chroma_mode > 3) { fail ("invalid chroma mode"); return false; }
     }
   } else {                                              // P macroblocks
     s.type_class = 3;
@@ -899,7 +956,7 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
     if (mbt <= 2) {
       const int np = mbt == 0 ? 1 : 2;
       int ref[2];
-      for (int i = 0; i < np; i++) { ref[i] = read_ref(); if (ref[i] >= nref) { fail ("ref_idx out of range"); return false; } }
+      for (int i = 0; i < np; i++) { ref[i] = read_ref(); if (ref[i] < 0 || ref[i] >= nref) { fail ("ref_idx out of range"); return false; } }
       for (int i = 0; i < np; i++) {
         int bx = 0, by = 0, bw = 4, bh = 4, shape = 0;
         if (mbt == 1) { bh = 2; by = i * 2; shape = 1 + i; } else if (mbt == 2) { bw = 2; bx = i * 2; shape = 3 + i; }
@@ -914,7 +971,7 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
     } else {
       int sub[4], ref[4] = {0, 0, 0, 0};
       for (int q = 0; q < 4; q++) { sub[q] = (int)br.ue(); if (sub[q] > 3) { fail ("invalid sub_mb_type"); return false; } m.sub_type[q] = (uint8_t) (1 << sub[q]); }
-      if (mbt == 3) for (int q = 0; q < 4; q++) { ref[q] = read_ref(); if (ref[q] >= nref) { fail ("ref_idx out of range"); return false; } }
+      if (mbt == 3) for (int q = 0; q < 4; q++) { ref[q] = read_ref(); if (ref[q] < 0 || ref[q] >= nref) { fail ("ref_idx out of range"); return false; } }
       for (int q = 0; q < 4; q++) { s.ref[q] = (int8_t)ref[q]; m.ref_idx[q] = (int8_t)ref[q]; y.ref_idx[q] = (int8_t)ref[q]; }
       for (int q = 0; q < 4; q++) {
         const int qx = (q & 1) * 2, qy = (q >> 1) * 2;
@@ -1024,7 +1081,7 @@ bool Parser::Impl::parse_slice_data_cavlc (BitReader& br, SliceCtx& c) {
     slice_run_before = 0;
     if (c.sh->slice_type != 2) {
       uint32_t run = br.ue();
-      if (br.err || (int)run > n - k) { fail ("invalid mb_skip_run"); return false; }
+      if (br.err || k < 0 || run > (uint32_t) (n - k)) { fail ("invalid mb_skip_run"); return false; }
       for (uint32_t i = 0; i < run; i++, k++, count++) if (!parse_mb_cavlc (br, c, k, qp_prev, true)) return false;
       slice_run_before = (int)run;
       more = br.more_rbsp_data();
@@ -1123,6 +1180,7 @@ int Parser::Impl::cabac_residual (Cabac& cb, int k, int sid, int cat, int blk, i
 bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, int& last_dqp, bool is_skip) {
   const Sps& S = *c.S; const Pps& P = *c.P; const SliceHeader& sh = *c.sh;
   const int sid = c.sid, w = cur->mb_w;
+  if (k < 0 || k >= cur->mb_w * cur->mb_h) { fail ("macroblock address out of range"); return false; }
   lh264_mb_t& m = cur->mbs[k];
   MbState& s = st[k];
   memset (&m, 0, sizeof (m));
@@ -1320,7 +1378,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
       for (int i = 0; i < np; i++) {
         const int bx = mbt == 2 ? i * 2 : 0, by = mbt == 1 ? i * 2 : 0;
         ref[i] = read_ref (bx, by);
-        if (ref[i] >= nref) { fail ("ref_idx out of range"); return false; }
+        if (ref[i] < 0 || ref[i] >= nref) { fail ("ref_idx out of range"); return false; }
         for (int q = 0; q < 4; q++) {
           const bool in = mbt == 0 || (mbt == 1 ? (q >> 1) == i : (q & 1) == i);
           if (in) { s.ref[q] = (int8_t)ref[i]; m.ref_idx[q] = (int8_t)ref[i]; }
@@ -1345,7 +1403,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
       }
       for (int q = 0; q < 4; q++) {
         ref[q] = read_ref ((q & 1) * 2, (q >> 1) * 2);
-        if (ref[q] >= nref) { fail ("ref_idx out of range"); return false; }
+        if (ref[q] < 0 || ref[q] >= nref) { fail ("ref_idx out of range"); return false; }
         s.ref[q] = (int8_t)ref[q]; m.ref_idx[q] = (int8_t)ref[q]; y.ref_idx[q] = (int8_t)ref[q];
       }
       for (int q = 0; q < 4; q++) {
@@ -1555,7 +1613,7 @@ int Parser::Impl::handle_nal (const uint8_t* nal, size_t len) {
       }
     }
     cur->slices.push_back (sl);
-    if (sh.first_mb >= S.mb_w * S.mb_h) { fail ("first_mb_in_slice out of range"); return -1; }
+    if (sh.first_mb < 0 || (uint32_t)sh.first_mb >= (uint32_t) (S.mb_w * S.mb_h)) { fail ("first_mb_in_slice out of range"); return -1; }
     last_hdr_bits = (int)br.pos; last_cabac = P.cabac;
     if (P.cabac ? !parse_slice_data_cabac (br, c) : !parse_slice_data_cavlc (br, c)) return -1;
     return 0;
@@ -1566,8 +1624,16 @@ int Parser::Impl::handle_nal (const uint8_t* nal, size_t len) {
 
 Parser::Parser() : d_ (new Impl (this)) {}
 Parser::~Parser() {}
-int Parser::feed_nal (const uint8_t* nal, size_t len) { return d_->handle_nal (nal, len); }
-void Parser::flush() { d_->finish_picture(); }
+// the two places every entry point goes through: nothing thrown below them (allocation failures, length errors of the standard
+// containers) crosses the C ABI - the stream is reported as failed instead
+int Parser::feed_nal (const uint8_t* nal, size_t len) {
+  try { return d_->handle_nal (nal, len); }
+  catch (const std::exception& e) { d_->fail (std::string ("internal: ") + e.what()); d_->cur.reset(); return -1; }
+}
+void Parser::flush() {
+  try { d_->finish_picture(); }
+  catch (const std::exception& e) { d_->fail (std::string ("internal: ") + e.what()); d_->cur.reset(); }
+}
 bool Parser::picture_in_progress_is_whole() const {
   if (!d_->cur) return false;
   for (uint8_t c : d_->cur->covered) if (!c) return false;

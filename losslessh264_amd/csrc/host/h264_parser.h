@@ -43,7 +43,7 @@ struct BitReader {
       pos += len;
       return (w >> (32 - len)) - 1;
     }
-    int z = 0; while (!u1()) { if (err || ++z > 32) { err = true; return 0; } } return z == 0 ? 0 : ((1u << z) - 1 + u (z));
+    int z = 0; while (!u1()) { if (err || ++z > 31) { err = true; return 0; } } return z == 0 ? 0 : ((1u << z) - 1 + u (z));
   }
   int32_t se() { uint32_t k = ue(); return (k & 1) ? (int32_t) ((k + 1) >> 1) : - (int32_t) (k >> 1); }
   bool byte_aligned() const { return (pos & 7) == 0; }

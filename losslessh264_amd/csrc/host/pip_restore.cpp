@@ -2,6 +2,7 @@
 // decoder/core/src/decode_slice.cpp (DS), decoder/core/src/macroblock_model.cpp (MM), decoder/core/inc/compression_stream.h (CS),
 // decoder/core/inc/decoded_macroblock.h (DM), decoder/core/src/decoder.cpp (DC).
 #include "pip_restore.h"
+#include <stdexcept>
 #include <string.h>
 #include <algorithm>
 #include "h264_parser.h"
@@ -889,7 +890,7 @@ void Restorer::write_mb_cabac (const Parser::HeaderInfo& H, int k, const MbDec* 
 // one slice: the macroblocks in scan order (WelsDecodeSliceForRecoding DS:2476-2830), each written out as CAVLC at once
 bool Restorer::decode_slice (const Parser::HeaderInfo& H) {
   const int w = H.mb_w, n = H.mb_w * H.mb_h;
-  if (n <= 0 || H.sh.first_mb >= n) { fail ("bad slice geometry"); return false; }
+  if (n <= 0 || H.sh.first_mb < 0 || H.sh.first_mb >= n) { fail ("bad slice geometry"); return false; }
   if ((int)ipm_.size() != n * 8) { ipm_.assign ((size_t)n * 8, 0); nxn_.assign (n, 0); }
   if (ws_n_ != n) { ws_.assign (n, WState()); ws_n_ = n; }
   sid_++;
@@ -1164,8 +1165,13 @@ int pip_restore (const uint8_t* main_stream, size_t main_len, const uint8_t* con
                  std::vector<uint8_t>& out, std::string& err) {
   err.clear();
   if (!main_stream || !tags || !tag_len) { err = "null argument"; return -1; }
-  Restorer r (tags, tag_len, n_tags, err);
-  return r.run (main_stream, main_len, out);
+  try {
+    Restorer r (tags, tag_len, n_tags, err);
+    return r.run (main_stream, main_len, out);
+  } catch (const std::exception& e) {      // allocation failures etc. on hostile input: reported, never thrown across the C ABI
+    err = std::string ("internal: ") + e.what();
+    return -1;
+  }
 }
 
 }  // namespace lh264host

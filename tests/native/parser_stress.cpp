@@ -50,8 +50,20 @@ static long run (const std::vector<uint8_t>& bs, size_t chunk) {
   return mbs;
 }
 
+
+#include "hostile.h"
+static int hostile_cases (long& total) {
+  int cases = 0;
+  for (uint64_t v : kHostileValues) for (int field = 0; field < 12; field++) for (int cab = 0; cab < 2; cab++) {
+    const std::vector<uint8_t> bs = hostile_stream (hostile_case (v, field, cab != 0), true);
+    for (size_t chunk = 0; chunk < 3; chunk++) { total += run (bs, chunk); cases++; }
+  }
+  return cases;
+}
+
 int main (int argc, char** argv) {
   long total = 0; int cases = 0;
+  cases += hostile_cases (total);
   for (int a = 1; a < argc; a++) {
     FILE* f = fopen (argv[a], "rb");
     if (!f) { perror (argv[a]); return 2; }

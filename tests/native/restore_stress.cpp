@@ -11,6 +11,7 @@
 #include <vector>
 #include "../../losslessh264_amd/csrc/host/h264_parser.h"
 #include "../../losslessh264_amd/csrc/host/pip_restore.h"
+#include "hostile.h"
 
 static uint32_t rng_state = 777;
 static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
@@ -35,6 +36,17 @@ static int restore (const std::vector<uint8_t>& main, const std::vector<std::vec
 
 int main (int argc, char** argv) {
   int cases = 0, failed_ok = 0;
+  {   // crafted default streams with no tagged streams: 32-bit Exp-Golomb values in every header field the restorer reads
+    std::vector<std::vector<uint8_t>> none (72);
+    std::vector<char> have (72, 0), all (72, 1);
+    std::vector<uint8_t> out;
+    for (uint64_t v : kHostileValues) for (int field = 0; field < 12; field++) for (int cab = 0; cab < 2; cab++) {
+      const std::vector<uint8_t> m = hostile_stream (hostile_case (v, field, cab != 0), true);
+      if (restore (m, none, have, out) != 0) failed_ok++;
+      if (restore (m, none, all, out) != 0) failed_ok++;      // every tagged stream present and empty
+      cases += 2;
+    }
+  }
   for (int a = 1; a < argc; a++) {
     const std::string base = argv[a];
     std::vector<uint8_t> orig, main;
