@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LH264_ABI_VERSION 1
+#define LH264_ABI_VERSION 2
 
 /* ---- macroblock types: the reference's own flag values (codec/common/inc/wels_common_defs.h:264-281) */
 #define LH264_MB_I4x4      0x0001
@@ -237,7 +237,8 @@ int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chai
  * coefficient symbols of lh264_ctx_index_chains go) and produces the byte string of every tagged stream exactly as
  * the reference's compressor writes it to <out>.pip.<tag> (ArithmeticCodedOutput / vpx_writer,
  * compression_stream.h:353-487, bitwriter.h:35-105; DynProb :87-115; emitInt / emitUEGkInt :523-591).
- * One workgroup (two waves) per stream: one keeps the adaptive state, lane t of the other the bool coder of tag slot t.  The adaptive priors live in
+ * The stream's symbols are binarised in parallel (one wave per macroblock); the adaptive probabilities are resolved by one
+ * workgroup per stream, 64 decisions per wave step; one lane per (stream, tag) runs the bool coder.  The adaptive priors live in
  * a per-stream open-addressing hash table in HBM (a cell = 16 packed DynProbs = 64 bytes), zero-filled by the caller. */
 #define LH264_N_TAG_SLOTS 40
 typedef struct lh264_code_job {
@@ -252,12 +253,16 @@ typedef struct lh264_code_stream {
   uint32_t* hash_cells_dev;    /* hash_cap * 16, zero-filled                                                */
   uint8_t*  out_dev;           /* LH264_N_TAG_SLOTS * out_cap bytes: slot t at t * out_cap                  */
   uint32_t* out_len_dev;       /* LH264_N_TAG_SLOTS lengths (0: tag never used); [LH264_N_TAG_SLOTS] = status (0 ok) */
-  uint32_t  hash_cap;          /* power of two                                                              */
+  uint32_t  hash_cap;          /* power of two, at most 1 << 20                                             */
   uint32_t  out_cap;
 } lh264_code_stream_t;
-/* tag id (billing.h) <-> slot: slot = tag for tags < 34, slot 34 = tag 69 (pad bits) */
+/* tag id (billing.h) <-> slot: slot = tag for tags < 34, slot 34 = tag 69 (pad bits).
+ * chain_first_dev: n_chains + 1 entries (stream c codes jobs_dev[chain_first[c] .. chain_first[c+1]-1] in order); n_jobs = all
+ * pictures, total_mbs = the sum of their n_mbs, max_mbs_per_frame = the largest n_mbs.  The call sizes its work memory (kept
+ * between calls, per device) from a count pass, so it synchronises hip_stream once in the middle; the tagged streams are complete
+ * when hip_stream has drained.  out_len_dev[LH264_N_TAG_SLOTS] != 0 reports 1: prior table full, 4: output overflow, 8: counter overflow. */
 int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
-                       int n_chains, void* hip_stream);
+                       int n_chains, int n_jobs, long long total_mbs, int max_mbs_per_frame, void* hip_stream);
 
 /* ---- host front end: Annex-B bitstream -> macroblock records ------------------------------
  * Replaces, for the records the hot path needs, the reference's WelsDecodeBs / ParseNonVclNal / slice-header parse /

@@ -99,7 +99,7 @@ CODE_JOB_DTYPE = np.dtype([("syn_syms", "<u8"), ("syn_off", "<u8"), ("ctx_syms",
 CODE_STREAM_DTYPE = np.dtype([("hash_keys", "<u8"), ("hash_cells", "<u8"), ("out", "<u8"), ("out_len", "<u8"), ("hash_cap", "<u4"), ("out_cap", "<u4")])
 N_TAG_SLOTS = 40
 assert CODE_JOB_DTYPE.itemsize == 40 and CODE_STREAM_DTYPE.itemsize == 40
-_SIGS["lh264_code_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
+_SIGS["lh264_code_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_void_p])
 EXPORTS = sorted(_SIGS)
 
 
@@ -151,5 +151,5 @@ CODE_JOB_DTYPE = np.dtype([("syn_syms", "<u8"), ("syn_off", "<u8"), ("ctx_syms",
 CODE_STREAM_DTYPE = np.dtype([("hash_keys", "<u8"), ("hash_cells", "<u8"), ("out", "<u8"), ("out_len", "<u8"), ("hash_cap", "<u4"), ("out_cap", "<u4")])
 N_TAG_SLOTS = 40
 assert CODE_JOB_DTYPE.itemsize == 40 and CODE_STREAM_DTYPE.itemsize == 40
-_SIGS["lh264_code_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
+_SIGS["lh264_code_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_void_p])
 EXPORTS = sorted(_SIGS)

@@ -11,6 +11,7 @@ class CoderSession:
     """ctx: a CtxSession over the same streams (frames must carry syn_syms / syn_off from parse_stream)"""
 
     def __init__(self, ctx, hash_cap=1 << 16, out_cap=1 << 16):
+        assert hash_cap <= 1 << 20 and hash_cap & (hash_cap - 1) == 0
         torch = ctx.torch
         self.ctx, self.torch, self.lib, dev = ctx, torch, ctx.lib, ctx.dev
         streams, rep = ctx.streams, ctx.replicate
@@ -64,6 +65,7 @@ class CoderSession:
         self.d_keys.zero_()
         self.d_cells.zero_()
         L.check(self.lib.lh264_code_chains(self.d_jobs.data_ptr(), self.ctx.d_first.data_ptr(), self.d_streams.data_ptr(), self.n_chains,
+                                           self.ctx.n_jobs, self.ctx.n_mbs_total, self.ctx.max_mbs,
                                            self.torch.cuda.current_stream(self.ctx.dev).cuda_stream))
 
     def tags(self, chain):

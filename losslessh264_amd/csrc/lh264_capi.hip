@@ -13,13 +13,23 @@
 #include "host/h264_parser.h"
 #include "host/capi_internal.h"
 #include "host/pip_restore.h"
+#include "lh264_coder.h"
+#include <mutex>
 
 namespace lh264 {
 __global__ void recon_chain_kernel (const lh264_frame_job_t* jobs, const int32_t* chain_first, int n_chains, int line_bytes);
 __global__ void ctx_nnz_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
 __global__ void ctx_inherit_chain_kernel (const lh264_ctx_job_t* jobs, const int32_t* chain_first, int n_chains);
 __global__ void ctx_symbols_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
-__global__ void coder_chain_kernel (const lh264_code_job_t* jobs, const int32_t* chain_first, const lh264_code_stream_t* streams, int n_chains);
+__global__ void coder_jobs_kernel (const lh264_code_job_t* jobs, const int32_t* chain_first, int n_jobs, int n_chains, uint32_t* jobmb0, uint32_t* job_chain, uint32_t* chain_info);
+__global__ void coder_count_kernel (const lh264_code_job_t* jobs, const uint32_t* jobmb0, const uint32_t* job_chain, int n_jobs, int blocks_per_job, uint16_t* cnt, uint32_t* chain_info);
+__global__ void coder_scan_kernel (const uint32_t* jobmb0, const int32_t* chain_first, const uint16_t* cnt, uint32_t* doff, uint32_t* chain_info, int n_chains);
+__global__ void coder_bases_kernel (uint32_t* chain_info, int n_chains, unsigned long long* totals);
+__global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* jobmb0, const uint32_t* job_chain, const lh264_code_stream_t* streams, int n_jobs,
+                                   int blocks_per_job, const uint32_t* doff, uint32_t* chain_info, uint32_t* D);
+__global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint32_t* D, uint16_t* Q, int n_chains);
+__global__ void coder_code_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, const uint16_t* Q, int n_chains, int groups);
+__global__ void coder_status_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, int n_chains);
 size_t wave_lds_bytes();
 size_t wg_lds_bytes();
 #ifdef LH264_STAMP
@@ -164,13 +174,78 @@ int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chai
   return LH264_OK;
 }
 
+// Work memory of the coder stages, kept between calls and grown on demand (one set per device; a call holds the device's lock, so
+// two host threads driving the same device take turns).
+namespace {
+struct CoderWs {
+  std::mutex mu;
+  void* small = nullptr; size_t small_cap = 0;     // job / macroblock / stream tables
+  void* big = nullptr; size_t big_cap = 0;         // decision words + tag lists
+  unsigned long long* totals_host = nullptr;       // page-locked, 2 x u64
+};
+CoderWs g_coder_ws[16];
+int grow (void** p, size_t* cap, size_t need) {
+  if (need <= *cap) return LH264_OK;
+  if (*p) { (void)hipFree (*p); *p = nullptr; *cap = 0; }
+  const size_t want = need + need / 8 + 4096;
+  hipError_t e = hipMalloc (p, want);
+  if (e != hipSuccess) return fail (LH264_E_HIP, "hipMalloc (coder work memory)", e);
+  *cap = want;
+  return LH264_OK;
+}
+size_t up256 (size_t v) { return (v + 255) & ~ (size_t)255; }
+}
+
 int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
-                       int n_chains, void* stream) {
+                       int n_chains, int n_jobs, long long total_mbs, int max_mbs_per_frame, void* stream) {
   if (lh264_device_count() <= 0) return fail (LH264_E_NODEVICE, "no HIP device visible");
-  if (!jobs_dev || !chain_first_dev || !streams_dev || n_chains < 0) return fail (LH264_E_ARG, "bad argument");
+  if (!jobs_dev || !chain_first_dev || !streams_dev || n_chains < 0 || n_jobs < 0 || total_mbs < 0 || max_mbs_per_frame <= 0) return fail (LH264_E_ARG, "bad argument");
   if (n_chains == 0) return LH264_OK;
-  hipLaunchKernelGGL (lh264::coder_chain_kernel, dim3 (n_chains), dim3 (128), 0, (hipStream_t)stream, jobs_dev, chain_first_dev, streams_dev, n_chains);
+  int dev = 0;
+  HIPCHK (hipGetDevice (&dev));
+  if (dev < 0 || dev >= 16) return fail (LH264_E_ARG, "device index out of range");
+  CoderWs& W = g_coder_ws[dev];
+  std::lock_guard<std::mutex> lock (W.mu);
+  hipStream_t st = (hipStream_t)stream;
+  if (!W.totals_host) HIPCHK (hipHostMalloc ((void**)&W.totals_host, 2 * sizeof (unsigned long long), hipHostMallocDefault));
+  // small tables
+  const size_t o_jobmb0 = 0, o_jobchain = up256 ((size_t) (n_jobs + 1) * 4), o_info = o_jobchain + up256 ((size_t) (n_jobs + 1) * 4),
+               o_totals = o_info + up256 ((size_t)n_chains * LH264_CODER_INFO_WORDS * 4), o_doff = o_totals + 256,
+               o_cnt = o_doff + up256 ((size_t)total_mbs * 4 + 4), small_need = o_cnt + up256 ((size_t)total_mbs * LH264_CODER_CNT_STRIDE * 2 + 2);
+  if (int rc = grow (&W.small, &W.small_cap, small_need)) return rc;
+  uint8_t* sm = (uint8_t*)W.small;
+  uint32_t* jobmb0 = (uint32_t*) (sm + o_jobmb0); uint32_t* job_chain = (uint32_t*) (sm + o_jobchain); uint32_t* info = (uint32_t*) (sm + o_info);
+  unsigned long long* totals = (unsigned long long*) (sm + o_totals); uint32_t* doff = (uint32_t*) (sm + o_doff); uint16_t* cnt = (uint16_t*) (sm + o_cnt);
+  const int bpj = (max_mbs_per_frame + 3) / 4;
+  hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, jobmb0, job_chain, info);
   HIPCHK (hipGetLastError());
+  if (n_jobs > 0 && total_mbs > 0) {
+    hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, jobmb0, job_chain, n_jobs, bpj, cnt, info);
+    HIPCHK (hipGetLastError());
+  }
+  hipLaunchKernelGGL (lh264::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, jobmb0, chain_first_dev, cnt, doff, info, n_chains);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_bases_kernel, dim3 (1), dim3 (1024), 0, st, info, n_chains, totals);
+  HIPCHK (hipGetLastError());
+  // the sizes of the decision words and of the tag lists are only known now
+  HIPCHK (hipMemcpyAsync (W.totals_host, totals, 2 * sizeof (unsigned long long), hipMemcpyDeviceToHost, st));
+  HIPCHK (hipStreamSynchronize (st));
+  const unsigned long long n_words = W.totals_host[0], n_q = W.totals_host[1];
+  const size_t o_q = up256 ((size_t)n_words * 4 + 256);
+  if (int rc = grow (&W.big, &W.big_cap, o_q + (size_t)n_q * 2 + 256)) return rc;
+  uint32_t* D = (uint32_t*)W.big; uint16_t* Q = (uint16_t*) ((uint8_t*)W.big + o_q);
+  if (n_jobs > 0 && total_mbs > 0) {
+    hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, jobmb0, job_chain, streams_dev, n_jobs, bpj, doff, info, D);
+    HIPCHK (hipGetLastError());
+  }
+  hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 (n_chains), dim3 (256), 0, st, streams_dev, info, D, Q, n_chains);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_status_kernel, dim3 ((n_chains + 255) / 256), dim3 (256), 0, st, streams_dev, info, n_chains);
+  HIPCHK (hipGetLastError());
+  const int groups = (n_chains + 63) / 64;
+  hipLaunchKernelGGL (lh264::coder_code_kernel, dim3 ((unsigned)groups * 35), dim3 (64), 0, st, streams_dev, info, Q, n_chains, groups);
+  HIPCHK (hipGetLastError());
+  // tag slots 35 .. LH264_N_TAG_SLOTS-1 do not exist: their lengths read 0
   return LH264_OK;
 }
 

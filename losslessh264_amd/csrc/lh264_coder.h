@@ -1,0 +1,26 @@
+// lh264_coder.h - internal layout shared by the coder kernels (lh264_coder.hip) and their launcher (lh264_capi.hip).
+#ifndef LH264_CODER_INTERNAL_H_
+#define LH264_CODER_INTERNAL_H_
+#include "../../include/lh264.h"
+
+// per-macroblock decision counts: [0 .. LH264_N_TAG_SLOTS-1] per tag slot (bit 15: the macroblock brings the tag's stream into
+// existence), [LH264_N_TAG_SLOTS] all decisions of the macroblock
+#define LH264_CODER_CNT_STRIDE (LH264_N_TAG_SLOTS + 1)
+
+// per-stream record (32-bit words)
+#define LH264_CODER_INFO_TAGBASE 0                                   /* [slot] first entry of the tag's list inside the stream's lists */
+#define LH264_CODER_INFO_TAGCNT  LH264_N_TAG_SLOTS                   /* [slot] entries                                                 */
+#define LH264_CODER_INFO_NDEC    (2 * LH264_N_TAG_SLOTS)             /* decisions of the stream                                        */
+#define LH264_CODER_INFO_NQ      (2 * LH264_N_TAG_SLOTS + 1)         /* list entries incl. padding                                     */
+#define LH264_CODER_INFO_TOUCH   (2 * LH264_N_TAG_SLOTS + 2)         /* 64-bit mask: tag streams that exist without a decision          */
+#define LH264_CODER_INFO_DBASE   (2 * LH264_N_TAG_SLOTS + 4)         /* 64-bit: first decision word of the stream                      */
+#define LH264_CODER_INFO_QBASE   (2 * LH264_N_TAG_SLOTS + 6)         /* 64-bit: first list entry of the stream                         */
+#define LH264_CODER_INFO_STATUS  (2 * LH264_N_TAG_SLOTS + 8)
+#define LH264_CODER_INFO_WORDS   96
+
+// status bits reported in out_len_dev[LH264_N_TAG_SLOTS]
+#define LH264_CODER_ST_TABLE_FULL 1
+#define LH264_CODER_ST_OUT_FULL   4
+#define LH264_CODER_ST_COUNT      8     /* more decisions in one macroblock than the counters hold */
+
+#endif

@@ -128,7 +128,7 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   for (int c = 0; c < n_chains; c++) {
     const size_t mbs = mb0[c + 1] - mb0[c];
     uint32_t hc = 1u << 16;
-    while (hc < mbs * 8 && hc < (1u << 22)) hc <<= 1;       // cells touched grow far slower than macroblocks; status 1 reports a full table
+    while (hc < mbs * 8 && hc < (1u << 20)) hc <<= 1;       // cells touched grow far slower than macroblocks; status 1 reports a full table
     hash_cap[c] = hc; key0[c + 1] = key0[c] + hc;
     out_cap[c] = (uint32_t)std::max<size_t> (1u << 16, 2 * len[idx[c]] + 4096);
     out0[c + 1] = out0[c] + (size_t)LH264_N_TAG_SLOTS * out_cap[c];
@@ -192,7 +192,7 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   if (trace_on()) hipDeviceSynchronize();
   const double t_d = now_s();
   int rc = lh264_ctx_index_chains (A.d_cj.as<lh264_ctx_job_t>(), A.d_first.as<int32_t>(), n_chains, (int)n_jobs, max_mbs, nullptr);
-  if (rc == LH264_OK) rc = lh264_code_chains (A.d_kj.as<lh264_code_job_t>(), A.d_first.as<int32_t>(), A.d_st.as<lh264_code_stream_t>(), n_chains, nullptr);
+  if (rc == LH264_OK) rc = lh264_code_chains (A.d_kj.as<lh264_code_job_t>(), A.d_first.as<int32_t>(), A.d_st.as<lh264_code_stream_t>(), n_chains, (int)n_jobs, (long long)n_mbs, max_mbs, nullptr);
   if (rc != LH264_OK || hipDeviceSynchronize() != hipSuccess) { fail_all (out, idx, rc != LH264_OK ? rc : LH264_E_HIP, "kernel launch failed"); return; }
   const double t_e = now_s();
   std::vector<uint32_t> lens ((size_t)n_chains * (LH264_N_TAG_SLOTS + 1));
@@ -202,7 +202,7 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   for (int c = 0; c < n_chains; c++) {
     lh264_compressed_t& r = *out[idx[c]];
     const uint32_t* L = &lens[(size_t)c * (LH264_N_TAG_SLOTS + 1)];
-    if (L[LH264_N_TAG_SLOTS] != 0) { r.status = LH264_E_HIP; r.error = "device coder status " + std::to_string (L[LH264_N_TAG_SLOTS]) + " (1: prior table full, 4: output overflow)"; continue; }
+    if (L[LH264_N_TAG_SLOTS] != 0) { r.status = LH264_E_HIP; r.error = "device coder status " + std::to_string (L[LH264_N_TAG_SLOTS]) + " (1: prior table full, 4: output overflow, 8: counter overflow)"; continue; }
     for (int slot = 0; slot < 35; slot++) if (L[slot]) {
         PackItem it; it.src = out0[c] + (size_t)slot * out_cap[c]; it.dst = packed_bytes; it.len = L[slot]; it.pad = (uint32_t)c << 8 | (uint32_t)slot;
         items.push_back (it);
