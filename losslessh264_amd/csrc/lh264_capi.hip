@@ -25,9 +25,9 @@ __global__ void coder_jobs_kernel (const lh264_code_job_t* jobs, const int32_t* 
 __global__ void coder_count_kernel (const lh264_code_job_t* jobs, const uint32_t* jobmb0, const uint32_t* job_chain, int n_jobs, int blocks_per_job, uint16_t* cnt, uint32_t* chain_info);
 __global__ void coder_scan_kernel (const uint32_t* jobmb0, const int32_t* chain_first, const uint16_t* cnt, uint32_t* doff, uint32_t* chain_info, int n_chains);
 __global__ void coder_bases_kernel (uint32_t* chain_info, int n_chains, unsigned long long* totals);
-__global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* jobmb0, const uint32_t* job_chain, const lh264_code_stream_t* streams, int n_jobs,
-                                   int blocks_per_job, const uint32_t* doff, uint32_t* chain_info, uint32_t* D);
-__global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint32_t* D, uint16_t* Q, int n_chains);
+__global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* jobmb0, const uint32_t* job_chain, int n_jobs,
+                                   int blocks_per_job, const uint32_t* doff, const uint32_t* chain_info, uint64_t* D);
+__global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint64_t* D, uint16_t* Q, int n_chains);
 __global__ void coder_code_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, const uint16_t* Q, int n_chains, int groups);
 __global__ void coder_status_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, int n_chains);
 size_t wave_lds_bytes();
@@ -231,14 +231,14 @@ int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_fi
   HIPCHK (hipMemcpyAsync (W.totals_host, totals, 2 * sizeof (unsigned long long), hipMemcpyDeviceToHost, st));
   HIPCHK (hipStreamSynchronize (st));
   const unsigned long long n_words = W.totals_host[0], n_q = W.totals_host[1];
-  const size_t o_q = up256 ((size_t)n_words * 4 + 256);
+  const size_t o_q = up256 ((size_t)n_words * 8 + 512);
   if (int rc = grow (&W.big, &W.big_cap, o_q + (size_t)n_q * 2 + 256)) return rc;
-  uint32_t* D = (uint32_t*)W.big; uint16_t* Q = (uint16_t*) ((uint8_t*)W.big + o_q);
+  uint64_t* D = (uint64_t*)W.big; uint16_t* Q = (uint16_t*) ((uint8_t*)W.big + o_q);
   if (n_jobs > 0 && total_mbs > 0) {
-    hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, jobmb0, job_chain, streams_dev, n_jobs, bpj, doff, info, D);
+    hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, jobmb0, job_chain, n_jobs, bpj, doff, info, D);
     HIPCHK (hipGetLastError());
   }
-  hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 (n_chains), dim3 (256), 0, st, streams_dev, info, D, Q, n_chains);
+  hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 (n_chains), dim3 (LH264_CODER_RESOLVE_THREADS), 0, st, streams_dev, info, D, Q, n_chains);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_status_kernel, dim3 ((n_chains + 255) / 256), dim3 (256), 0, st, streams_dev, info, n_chains);
   HIPCHK (hipGetLastError());

@@ -18,9 +18,14 @@
 #define LH264_CODER_INFO_STATUS  (2 * LH264_N_TAG_SLOTS + 8)
 #define LH264_CODER_INFO_WORDS   96
 
+// threads of a coder_resolve_kernel workgroup (one workgroup per stream)
+#define LH264_CODER_RESOLVE_WAVES 8
+#define LH264_CODER_RESOLVE_THREADS (64 * LH264_CODER_RESOLVE_WAVES)
+
 // status bits reported in out_len_dev[LH264_N_TAG_SLOTS]
 #define LH264_CODER_ST_TABLE_FULL 1
 #define LH264_CODER_ST_OUT_FULL   4
 #define LH264_CODER_ST_COUNT      8     /* more decisions in one macroblock than the counters hold */
+#define LH264_CODER_ST_HANDOFF    16    /* internal: a wave step waited too long for its turn (the result is wrong) */
 
 #endif

@@ -217,25 +217,16 @@ struct CountSink {
     else if (s3 < 0) { s3 = sl; n3 = 1; } else many = true;
   }
 };
-// find-or-insert in the stream's open-addressing table (key 0 = empty; zero-filled cells are a prior's initial state).  Lanes of
-// any workgroup insert concurrently: the compare-and-swap decides, and a slot's key never changes once set.
+// a decision word (64 bits): the low dword is the key of the prior's cell (LH264_PRIOR form; 0 for a raw bit), the high dword
+// bits 0..3 the place in the cell, bit 4 the bit, bits 5..10 the tag slot, bit 31 "raw bit" (coded with TEST_PROB)
 struct EmitSink {
-  GLB uint32_t* D; GLB uint32_t* keys; uint32_t mask, pos, slot; int status;
+  GLB uint64_t* D; uint32_t pos, key;
   __device__ __forceinline__ void touch (int) {}
-  __device__ __forceinline__ void cell (uint32_t key) {
-    const uint32_t want = key + 1u;
-    uint32_t h = (key * 0x9E3779B1u) >> 7;
-    for (int p = 0; p < 512; p++, h++) {
-      const uint32_t s = h & mask;
-      uint32_t kv = __hip_atomic_load ((uint32_t*) (uintptr_t) (keys + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (kv == 0u) { kv = atomicCAS ((uint32_t*) (uintptr_t) (keys + s), 0u, want); if (kv == 0u) kv = want; }
-      if (kv == want) { slot = s; return; }
-    }
-    status |= LH264_CODER_ST_TABLE_FULL; slot = 0;
-  }
+  __device__ __forceinline__ void cell (uint32_t k) { key = k; }
   __device__ __forceinline__ void dec (int j, int bit, int tag) {
-    const uint32_t t = (uint32_t)tag_slot (tag) << 25 | (uint32_t) (bit & 1) << 24;
-    D[pos++] = (j & 0xff) == 0xff ? (0x80000000u | t) : (slot | (uint32_t) (j & 15) << 20 | t);
+    const uint32_t t = (uint32_t)tag_slot (tag) << 5 | (uint32_t) (bit & 1) << 4;
+    const bool raw = (j & 0xff) == 0xff;
+    D[pos++] = raw ? (uint64_t) (0x80000000u | t) << 32 : ((uint64_t) (t | (uint32_t) (j & 15)) << 32 | key);
   }
 };
 
@@ -265,6 +256,7 @@ coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __r
   for (int c = tid; c < n_chains; c += 1024) {
     for (int j = chain_first[c]; j < chain_first[c + 1]; j++) job_chain[j] = (uint32_t)c;
     chain_info[(size_t)c * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS] = 0;
+    for (int q = 90; q < 96; q++) chain_info[(size_t)c * LH264_CODER_INFO_WORDS + q] = 0;
   }
 }
 
@@ -385,8 +377,8 @@ coder_bases_kernel (uint32_t* __restrict__ chain_info, int n_chains, unsigned lo
 // ---- kernel 4: the decision words, in coding order -------------------------------------------------------------------------
 __global__ void __launch_bounds__ (256)
 coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ jobmb0, const uint32_t* __restrict__ job_chain,
-                   const lh264_code_stream_t* __restrict__ streams, int n_jobs, int blocks_per_job, const uint32_t* __restrict__ doff,
-                   uint32_t* __restrict__ chain_info, uint32_t* __restrict__ D) {
+                   int n_jobs, int blocks_per_job, const uint32_t* __restrict__ doff, const uint32_t* __restrict__ chain_info,
+                   uint64_t* __restrict__ D) {
   const int ji = blockIdx.x / blocks_per_job;
   if (ji >= n_jobs) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -394,8 +386,6 @@ coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __
   const uint32_t chain = job_chain[ji];
   const uint32_t* I = chain_info + (size_t)chain * LH264_CODER_INFO_WORDS;
   const unsigned long long dbase = (unsigned long long)I[LH264_CODER_INFO_DBASE] | (unsigned long long)I[LH264_CODER_INFO_DBASE + 1] << 32;
-  const lh264_code_stream_t* S = streams + chain;
-  int status = 0;
   for (int k = (blockIdx.x % blocks_per_job) * 4 + wave; k < J->n_mbs; k += blocks_per_job * 4) {
     const MbSyms m = mb_syms (J, k, lane);
     uint32_t running = doff[(size_t)jobmb0[ji] + (size_t)k];
@@ -410,15 +400,12 @@ coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __
       }
       const int incl = wave_scan_add (ts.n);
       if (i < m.total && ts.n > 0) {
-        EmitSink es; es.D = glb<uint32_t> (D) + dbase; es.keys = glb<uint32_t> (S->hash_keys_dev); es.mask = S->hash_cap - 1u;
-        es.pos = running + (uint32_t) (incl - ts.n); es.slot = 0; es.status = 0;
+        EmitSink es; es.D = glb<uint64_t> (D) + dbase; es.pos = running + (uint32_t) (incl - ts.n); es.key = 0;
         binarize (es, (uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24));
-        status |= es.status;
       }
       running += (uint32_t)__builtin_amdgcn_readlane (incl, 63);
     }
   }
-  if (__ballot (status != 0) && lane == 0) atomicOr (&chain_info[(size_t)chain * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_TABLE_FULL);
 }
 
 // ---- kernel 5: the probability every decision is coded with -----------------------------------------------------------------
@@ -435,54 +422,103 @@ template <int NBITS> __device__ __forceinline__ void wave_match (uint32_t key, u
 }
 __device__ __forceinline__ int below (uint32_t lo, uint32_t hi) { return (int)__builtin_amdgcn_mbcnt_hi (hi, __builtin_amdgcn_mbcnt_lo (lo, 0u)); }
 
-#define RS_WAVES 4
-#define RS_ROWS 1024             // cells in the LDS cache (64 bytes each)
-#define RS_FLUSH 384             // write everything back and start over above this many cells (a step of the workgroup adds <= 256)
+// The counters of a DynProb as the resolve kernel keeps them: c0 | c1 << 10, NOT yet halved when their sum has reached 513 - the
+// reference computes the next probability before it halves (DynProb::update, :101-113), so the probability of the next decision always
+// follows from the stored pair, and the halving is done by the next reader.  An entry of the LDS cache (and of the spill table in HBM) is
+// 64 bits: counters in bits 0..19, the DynProb's key (cell key << 4 | place, 36 bits) in bits 20..55, bit 63 set.  All zero = free.
+#define RS_WAVES LH264_CODER_RESOLVE_WAVES
+#define RS_SLOTS 8192            // DynProbs in the LDS cache
+#define RS_CHECK 4               // the fill of the cache is looked at every RS_CHECK workgroup steps (that many steps insert <= 2048)
+#define RS_FLUSH 4600            // everything goes to the spill table and the cache starts over above this many
 struct ResolveLds {
-  uint32_t rows[RS_ROWS][16];
-  uint32_t rkeys[RS_ROWS];       // table slot + 1 of the cell a row holds; 0: free
+  unsigned long long ent[RS_SLOTS];
   uint32_t cursor[LH264_N_TAG_SLOTS];
   uint32_t test_prob;            // TEST_PROB: the DynProb shared by the raw bits of all tags
   uint32_t ticket;               // the next wave step allowed into the serial section
-  uint32_t nadd[4];              // cells inserted for workgroup step it, at [it & 3]
+  uint32_t nres;                 // entries in the cache
   uint32_t scratch[RS_WAVES][64];
 };
+__device__ __forceinline__ unsigned long long rs_key (uint32_t lo, uint32_t hi) { return (unsigned long long)lo << 4 | (unsigned long long) (hi & 15u); }
+#define RS_ENT_KEY(e) (((e) >> 20) & 0xfffffffffull)
+#define RS_ENT_MAKE(key, st) (0x8000000000000000ull | (unsigned long long) (key) << 20 | (unsigned long long) (st))
+__device__ __forceinline__ uint32_t rs_hash (unsigned long long key) { return ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t) (key >> 32) * 0x85EBCA6Bu); }
 
-struct RowRef { int row; bool miss; u32x4 f0, f1, f2, f3; };
-// the row of table slot `slot` in the cache (inserted if absent; the inserting lane fetches the cell)
-__device__ __forceinline__ void rs_lookup (LDS ResolveLds& S, const GLB uint32_t* cells, uint32_t w, bool valid, RowRef& R) {
-  R.row = 0; R.miss = false;
-  if (valid && !(w & 0x80000000u)) {
-    const uint32_t slot = w & 0xfffffu, want = slot + 1u;
-    uint32_t h = (slot * 0x9E3779B1u) >> 22;
-    for (int tries = 0; tries < 2 * RS_ROWS; tries++) {          // (the flush policy keeps the cache at most 7/8 full: bounded anyway)
-      h &= RS_ROWS - 1;
-      volatile LDS uint32_t* kp = &S.rkeys[h];
-      uint32_t kv = *kp;
-      if (kv == 0u) {
-        uint32_t expect = 0u;
-        if (__hip_atomic_compare_exchange_strong (&S.rkeys[h], &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { R.miss = true; break; }
-        kv = expect;
+// the spill table: open addressing over the stream's `hash_cells_dev` memory (zero-filled by the caller), entries as above.  Only this
+// workgroup touches it; its accesses go to L2 (agent scope), never through this CU's L1.
+__device__ __forceinline__ void spill_put (GLB unsigned long long* T, uint32_t tmask, unsigned long long key, uint32_t st) {
+  const unsigned long long val = RS_ENT_MAKE (key, st);
+  uint32_t h = rs_hash (key) >> 8;
+  for (uint32_t tries = 0; tries <= tmask; tries++, h++) {
+    unsigned long long* p = (unsigned long long*) (uintptr_t) (T + (h & tmask));
+    unsigned long long cur = __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0ull) { cur = atomicCAS (p, 0ull, val); if (cur == 0ull) return; }
+    if (RS_ENT_KEY (cur) == key) { __hip_atomic_store (p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }      // (a key sits in one cache entry: nobody else writes it now)
+  }
+}
+__device__ __forceinline__ uint32_t spill_get (const GLB unsigned long long* T, uint32_t tmask, unsigned long long key, unsigned long long first) {
+  uint32_t h = rs_hash (key) >> 8;
+  unsigned long long cur = first;                   // the entry at the key's home slot, requested a step ago
+  for (uint32_t tries = 0; tries <= tmask; tries++) {
+    if (cur == 0ull) return 0u;
+    if (RS_ENT_KEY (cur) == key) return (uint32_t)cur & 0xfffffu;
+    h++;
+    cur = __hip_atomic_load ((unsigned long long*) (uintptr_t) (T + (h & tmask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return 0u;
+}
+
+struct SlotRef { int idx; bool miss, inserted; unsigned long long first; };
+// the cache entry of the DynProb of decision word (lo, hi): inserted with fresh counters if absent; if counters may have been spilled,
+// the inserting lane asks the spill table (answer taken by rs_land)
+__device__ __forceinline__ void rs_lookup (LDS ResolveLds& S, const GLB unsigned long long* T, uint32_t tmask, uint32_t lo, uint32_t hi, bool valid, bool spilled, SlotRef& R) {
+  R.idx = 0; R.miss = false; R.inserted = false; R.first = 0ull;
+  if (valid && !(hi & 0x80000000u)) {
+    const unsigned long long key = rs_key (lo, hi), fresh = RS_ENT_MAKE (key, 0u);
+    uint32_t h = rs_hash (key) >> 19;
+    for (int tries = 0; tries < 2 * RS_SLOTS; tries++) {      // (the flush policy keeps the cache at most 7/8 full: bounded anyway)
+      h &= RS_SLOTS - 1;
+      unsigned long long cur = * (volatile LDS unsigned long long*)&S.ent[h];
+      if (cur == 0ull) {
+        unsigned long long expect = 0ull;
+        if (__hip_atomic_compare_exchange_strong (&S.ent[h], &expect, fresh, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { R.miss = true; break; }
+        cur = expect;
       }
-      if (kv == want) break;
+      if (RS_ENT_KEY (cur) == key) break;
       h++;
     }
-    R.row = (int)h;
-    if (R.miss) {
-      const GLB u32x4* src = (const GLB u32x4*) (cells + (size_t)slot * 16);
-      R.f0 = src[0]; R.f1 = src[1]; R.f2 = src[2]; R.f3 = src[3];
-    }
+    R.idx = (int)h;
+    R.inserted = R.miss;
+    R.miss = R.miss && spilled;                                // before the first flush a new DynProb is simply fresh
+    if (R.miss) R.first = __hip_atomic_load ((unsigned long long*) (uintptr_t) (T + ((rs_hash (key) >> 8) & tmask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__device__ __forceinline__ void rs_land (LDS ResolveLds& S, const RowRef& R) {
+// the counters the spill table holds for an entry inserted by rs_lookup go into the entry (it has not been used yet)
+__device__ __forceinline__ void rs_land (LDS ResolveLds& S, const GLB unsigned long long* T, uint32_t tmask, uint32_t lo, uint32_t hi, SlotRef& R) {
   if (R.miss) {
-    LDS u32x4* dst = (LDS u32x4*)S.rows[R.row];
-    dst[0] = R.f0; dst[1] = R.f1; dst[2] = R.f2; dst[3] = R.f3;
+    const uint32_t st = spill_get (T, tmask, rs_key (lo, hi), R.first);
+    volatile LDS uint32_t* p = (volatile LDS uint32_t*)&S.ent[R.idx];
+    if (st) *p = (*p & 0xfff00000u) | st;
+    R.miss = false;
   }
+}
+__device__ __forceinline__ void rs_count (LDS ResolveLds& S, bool inserted, int lane) {
+  const unsigned long long mm = __ballot (inserted);
+  if (mm && lane == 0) __hip_atomic_fetch_add (&S.nres, (uint32_t)__popcll (mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// LDS traffic of this wave done, then the workgroup barrier (not __syncthreads: it would also wait for the memory operations in flight)
+__device__ __forceinline__ void rs_barrier() {
+  asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile ("" ::: "memory");
 }
 
+// Workgroup step `it` = rounds it * RS_WAVES .. + RS_WAVES - 1 of 64 decisions, one per wave, through the ticketed serial section in
+// round order; nothing else synchronises the waves of a step.  Software pipeline per wave: the decision words are fetched five steps
+// ahead; the cache entries of a round are looked up two steps before the round is resolved (a DynProb that is not in the cache is
+// inserted then, and its spilled counters requested); the answer goes into the entry one step later, BEFORE the wave's own turn of
+// that step - every round that uses the entry comes later in ticket order than that turn, so it sees the counters.
 __global__ void __launch_bounds__ (RS_WAVES * 64)
-coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t* __restrict__ chain_info, const uint32_t* __restrict__ D,
+coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t* __restrict__ chain_info, const uint64_t* __restrict__ D,
                       uint16_t* __restrict__ Q, int n_chains) {
   __shared__ ResolveLds Sg;
   LDS ResolveLds& S = * (LDS ResolveLds*) (uintptr_t) (uint32_t) (uintptr_t)&Sg;
@@ -491,118 +527,122 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t* I = chain_info + (size_t)chain * LH264_CODER_INFO_WORDS;
   const uint32_t n = I[LH264_CODER_INFO_NDEC];
-  const GLB uint32_t* Dc = glb<const uint32_t> (D) + ((unsigned long long)I[LH264_CODER_INFO_DBASE] | (unsigned long long)I[LH264_CODER_INFO_DBASE + 1] << 32);
+  const GLB uint64_t* Dc = glb<const uint64_t> (D) + ((unsigned long long)I[LH264_CODER_INFO_DBASE] | (unsigned long long)I[LH264_CODER_INFO_DBASE + 1] << 32);
   GLB uint16_t* Qc = glb<uint16_t> (Q) + ((unsigned long long)I[LH264_CODER_INFO_QBASE] | (unsigned long long)I[LH264_CODER_INFO_QBASE + 1] << 32);
-  GLB uint32_t* cells = glb<uint32_t> (streams[chain].hash_cells_dev);
-  for (int i = tid; i < RS_ROWS; i += RS_WAVES * 64) S.rkeys[i] = 0;
+  GLB unsigned long long* T = glb<unsigned long long> (streams[chain].hash_cells_dev);
+  const uint32_t tmask = streams[chain].hash_cap * 8u - 1u;            // hash_cap cells of 64 bytes = 8 entries each
+  for (int i = tid; i < RS_SLOTS; i += RS_WAVES * 64) S.ent[i] = 0ull;
   if (tid < LH264_N_TAG_SLOTS) S.cursor[tid] = I[LH264_CODER_INFO_TAGBASE + tid];
-  if (tid == 0) { S.test_prob = 0; S.ticket = 0; S.nadd[0] = S.nadd[1] = S.nadd[2] = S.nadd[3] = 0; }
+  if (tid == 0) { S.test_prob = 0; S.ticket = 0; S.nres = 0; }
   __syncthreads();
   const uint32_t n_rounds = (n + 63u) >> 6;
   const uint32_t n_iter = (n_rounds + RS_WAVES - 1) / RS_WAVES;
   uint32_t r = (uint32_t)wave;
-  uint32_t w_cur = 0; bool v_cur = r * 64u + (uint32_t)lane < n;
-  if (v_cur) w_cur = Dc[r * 64u + (uint32_t)lane];
-  RowRef cur;
-  rs_lookup (S, cells, w_cur, v_cur, cur);
-  { const unsigned long long mm = __ballot (cur.miss); if (mm && lane == 0) __hip_atomic_fetch_add (&S.nadd[0], (uint32_t)__popcll (mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-  rs_land (S, cur);
-  int row_cur = cur.row;
+  auto fetch = [&] (uint32_t round) -> uint64_t { const uint32_t i = round * 64u + (uint32_t)lane; return i < n ? Dc[i] : 0ull; };
+  auto is_valid = [&] (uint32_t round) -> bool { return round * 64u + (uint32_t)lane < n; };
+  // rounds r (resolved in this step), r + W (looked up; a spilled answer is taken in this step), r + 2W (looked up in this step), then the words
+  uint64_t w0 = fetch (r), w1 = fetch (r + RS_WAVES), w2 = fetch (r + 2 * RS_WAVES);
+  uint64_t q0 = fetch (r + 3 * RS_WAVES), q1 = fetch (r + 4 * RS_WAVES), q2 = fetch (r + 5 * RS_WAVES);
+  bool spilled = false;
+  SlotRef e0, e1;
+  rs_lookup (S, T, tmask, (uint32_t)w0, (uint32_t) (w0 >> 32), is_valid (r), false, e0);
+  rs_lookup (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), is_valid (r + RS_WAVES), false, e1);
+  rs_count (S, e0.inserted, lane); rs_count (S, e1.inserted, lane);
   __syncthreads();
-  uint32_t resident = 0;
   for (uint32_t it = 0; it < n_iter; it++) {
-    const uint32_t rn = r + RS_WAVES;
-    const bool v_next = rn * 64u + (uint32_t)lane < n;
-    uint32_t w_next = 0;
-    if (v_next) w_next = Dc[rn * 64u + (uint32_t)lane];
-    const bool round_ok = r < n_rounds;
-    // the insertion counter of the step after next: last read two barriers ago, next written behind this step's barrier
-    if (tid == 0) * (volatile LDS uint32_t*)&S.nadd[(it + 2u) & 3u] = 0;
+    const bool v_cur = is_valid (r), round_ok = r < n_rounds;
+    const uint32_t w_hi = (uint32_t) (w0 >> 32);
     // ---- what does not depend on the adaptive state: who shares my DynProb, who shares my tag ----------------------------------------
-    const bool raw = (w_cur & 0x80000000u) != 0;
-    const int j = (int) ((w_cur >> 20) & 15u), bit = (int) ((w_cur >> 24) & 1u), tag = (int) ((w_cur >> 25) & 63u);
+    const bool raw = (w_hi & 0x80000000u) != 0;
+    const int bit = (int) ((w_hi >> 4) & 1u), tag = (int) ((w_hi >> 5) & 63u);
     const unsigned long long valid = __ballot (v_cur);
-    const uint32_t dkey = raw ? 0x7fffu : ((uint32_t)row_cur << 4 | (uint32_t)j);        // 10 + 4 bits; 0x7fff: TEST_PROB
+    const uint32_t dkey = raw ? 0x3fffu : (uint32_t)e0.idx;                  // 13 bits of cache entry; 0x3fff: TEST_PROB
     uint32_t slo, shi, tlo, thi;
-    wave_match<15> (dkey, valid, slo, shi);
+    wave_match<14> (dkey, valid, slo, shi);
     wave_match<6> ((uint32_t)tag, valid, tlo, thi);
     const unsigned long long zm = __ballot (v_cur && bit == 0);
     const int rank = below (slo, shi), nn = __popc (slo) + __popc (shi);
     const int z = below (slo & (uint32_t)zm, shi & (uint32_t) (zm >> 32));
     const int trank = below (tlo, thi), tn = __popc (tlo) + __popc (thi);
     const int head = slo ? __ffs ((int)slo) - 1 : 32 + __ffs ((int)shi) - 1;
-    // ---- the rows of the next step (inserting does not disturb the steps in flight: they use rows they found earlier) -------------------
-    RowRef nx;
-    rs_lookup (S, cells, w_next, v_next, nx);
-    { const unsigned long long mm = __ballot (nx.miss); if (mm && lane == 0) __hip_atomic_fetch_add (&S.nadd[(it + 1u) & 3u], (uint32_t)__popcll (mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    // spilled counters requested a step ago: into the entries now (before this wave's turn, see above)
+    rs_land (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), e1);
     // ---- the serial section: counters in, counters out -------------------------------------------------------------------------------
-    uint32_t prob = 128u, qpos = 0;
     if (round_ok) {
-      // (the spin is bounded so that a broken hand-off ends as a wrong result, not as a hung GPU)
-      { volatile LDS uint32_t* tk = &S.ticket; for (uint32_t spins = 0; *tk != r && spins < (1u << 24); spins++) __builtin_amdgcn_s_sleep (0); }
-      asm volatile ("" ::: "memory");
-      volatile LDS uint32_t* sp = raw ? &S.test_prob : &S.rows[row_cur][j];
+      volatile LDS uint32_t* sp = raw ? &S.test_prob : (volatile LDS uint32_t*)&S.ent[e0.idx];
       volatile LDS uint32_t* cp = &S.cursor[tag];
+      {   // (the spin is bounded so that a broken hand-off ends as a wrong result with a status bit, not as a hung GPU)
+        volatile LDS uint32_t* tk = &S.ticket;
+        uint32_t spins = 0;
+        for (; *tk != r && spins < (1u << 16); spins++) __builtin_amdgcn_s_sleep (0);
+        if (spins >= (1u << 16) && lane == 0) atomicOr (&chain_info[(size_t)chain * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_HANDOFF);
+      }
+      asm volatile ("" ::: "memory");
       uint32_t st = 0, cb = 0;
       if (v_cur) { st = *sp; cb = *cp; }
       const uint32_t c0 = st & 1023u, c1 = (st >> 10) & 1023u;
+      const bool lazy = c0 + c1 > 512u;                                     // the halving the last decision left to its successor
+      const uint32_t f0 = lazy ? (c0 + 1u) >> 1 : c0, f1 = lazy ? (c1 + 1u) >> 1 : c1;
       // counters before this lane's decision: the group's earlier zeros and ones on top of the stored ones
-      uint32_t a0 = c0 + (uint32_t)z, a1 = c1 + (uint32_t) (rank - z);      // what the probability is computed from
-      uint32_t b0 = a0, b1 = a1;                                            // what the update starts from
-      const int t = 512 - (int) (c0 + c1);          // the decision of this rank pushes the sum over 512: the counters are halved after it
+      uint32_t b0 = f0 + (uint32_t)z, b1 = f1 + (uint32_t) (rank - z);
+      uint32_t a0 = rank == 0 ? c0 : b0, a1 = rank == 0 ? c1 : b1;         // what the probability is computed from
+      const int t = 512 - (int) (f0 + f1);          // the decision of this rank brings the sum to 513: halved before the decision after the next
       if (__ballot (v_cur && nn > t + 1)) {
-        // a rescale inside the group: ranks > t + 1 count on from the halved counters, rank t + 1 is still coded with the
-        // probability computed before the halving (DynProb::update computes the probability first, :101-113)
+        // a halving inside the group: rank t + 1 is still coded from the pair as it stands after rank t, but counts on from the halved
+        // pair, as do the ranks behind it
         LDS uint32_t* sc = S.scratch[wave];
         if (v_cur && rank == t + 1) sc[head] = (uint32_t)z;                 // zeros among ranks 0..t
         __builtin_amdgcn_wave_barrier();
         if (v_cur && rank > t) {
           const uint32_t zt = * (volatile LDS uint32_t*)&sc[head];
-          const uint32_t h0 = (c0 + zt + 1u) >> 1, h1 = (c1 + (uint32_t) (t + 1) - zt + 1u) >> 1;
+          const uint32_t h0 = (f0 + zt + 1u) >> 1, h1 = (f1 + (uint32_t) (t + 1) - zt + 1u) >> 1;
           b0 = h0 + ((uint32_t)z - zt); b1 = h1 + ((uint32_t) (rank - z) - ((uint32_t) (t + 1) - zt));
           if (rank > t + 1) { a0 = b0; a1 = b1; }
         }
         __builtin_amdgcn_wave_barrier();
       }
-      if (v_cur && rank == nn - 1) *sp = dp_after (b0, b1, bit);
+      if (v_cur && rank == nn - 1) *sp = (st & 0xfff00000u) | (b0 + (uint32_t) (bit ^ 1)) | (b1 + (uint32_t)bit) << 10;
       if (v_cur && trank == tn - 1) *cp = cb + (uint32_t)tn;
       asm volatile ("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) { volatile LDS uint32_t* tk = &S.ticket; *tk = r + 1u; }
       // ---- afterwards: the probability, and the entry of the tag's list ------------------------------------------------------------------
-      prob = rank == 0 ? (uint32_t)dp_prob (st) : dp_ratio (a0, a1);
-      qpos = cb + (uint32_t)trank;
-      if (v_cur) Qc[qpos] = (uint16_t) (prob << 1 | (uint32_t)bit);
+      const uint32_t prob = dp_ratio (a0, a1);
+      if (v_cur) Qc[cb + (uint32_t)trank] = (uint16_t) (prob << 1 | (uint32_t)bit);
     }
-    rs_land (S, nx);
-    __syncthreads();
-    resident += * (volatile LDS uint32_t*)&S.nadd[it & 3u];
-    int row_next = nx.row;
-    if (resident > RS_FLUSH) {
-      // the cache is filling up: every cell back to the table, start over with the cells of the next step
-      if (tid == 0) * (volatile LDS uint32_t*)&S.nadd[(it + 1u) & 3u] = 0;      // they are inserted (and counted) again below
-      for (int i = tid; i < RS_ROWS; i += RS_WAVES * 64) {
-        const uint32_t kv = S.rkeys[i];
-        if (kv) {
-          GLB u32x4* dst = (GLB u32x4*) (cells + (size_t) (kv - 1u) * 16);
-          const LDS u32x4* src = (const LDS u32x4*)S.rows[i];
-          dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
-          S.rkeys[i] = 0;
+    // ---- the entries of the round two steps ahead (inserting does not disturb the rounds in flight: they use entries they found earlier) --
+    SlotRef e2;
+    rs_lookup (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), is_valid (r + 2 * RS_WAVES), spilled, e2);
+    rs_count (S, e2.inserted, lane);
+    if ((it % RS_CHECK) == RS_CHECK - 1) {
+      // ---- every few steps: is the cache filling up? ----------------------------------------------------------------------------------
+      rs_barrier();
+      const uint32_t resident = * (volatile LDS uint32_t*)&S.nres;
+      rs_barrier();
+      if (resident > RS_FLUSH) {
+        // every DynProb to the spill table, then the cache starts over with the entries of the two rounds in flight
+        rs_land (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), e1);
+        rs_land (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), e2);
+        rs_barrier();
+        for (int i = tid; i < RS_SLOTS; i += RS_WAVES * 64) {
+          const unsigned long long e = S.ent[i];
+          if (e) { spill_put (T, tmask, RS_ENT_KEY (e), (uint32_t)e & 0xfffffu); S.ent[i] = 0ull; }
         }
+        if (tid == 0) S.nres = 0;
+        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+        rs_barrier();
+        spilled = true;
+        rs_lookup (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), is_valid (r + RS_WAVES), true, e1);
+        rs_lookup (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), is_valid (r + 2 * RS_WAVES), true, e2);
+        rs_count (S, e1.inserted, lane); rs_count (S, e2.inserted, lane);
+        rs_land (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), e1);
+        rs_land (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), e2);
+        rs_barrier();
       }
-      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");       // the cells are read again below: not from a line this CU cached before the write-back
-      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-      RowRef again;
-      rs_lookup (S, cells, w_next, v_next, again);
-      { const unsigned long long mm = __ballot (again.miss); if (mm && lane == 0) __hip_atomic_fetch_add (&S.nadd[(it + 1u) & 3u], (uint32_t)__popcll (mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      rs_land (S, again);
-      row_next = again.row;
-      resident = 0;
-      __syncthreads();
     }
-    r = rn; w_cur = w_next; v_cur = v_next; row_cur = row_next;
+    r += RS_WAVES;
+    w0 = w1; w1 = w2; w2 = q0; q0 = q1; q1 = q2; q2 = fetch (r + 5 * RS_WAVES);
+    e0 = e1; e1 = e2;
   }
 }
 
@@ -674,9 +714,15 @@ coder_code_kernel (const lh264_code_stream_t* __restrict__ streams, const uint32
   GLB uint8_t* o = glb<uint8_t> (S->out_dev) + (size_t)slot * cap;
   Bc bc;
   bc.pos = 0; bc.low = 0; bc.range = 255; bc.count = -24; bc.ffrun = 0; bc.pending = -1; bc.last = 0;
-  for (uint32_t q = 0; q < n; q += 8) {
-    const u32x4 v = src[q >> 3];
+  // the list is read four 16-byte pieces ahead of the coder (each piece is a memory round trip of its own for every lane)
+  const uint32_t pieces = (n + 7u) >> 3;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 p0 = pieces > 0 ? src[0] : zero4, p1 = pieces > 1 ? src[1] : zero4, p2 = pieces > 2 ? src[2] : zero4, p3 = pieces > 3 ? src[3] : zero4;
+  for (uint32_t c = 0; c < pieces; c++) {
+    const u32x4 v = p0;
+    p0 = p1; p1 = p2; p2 = p3; p3 = c + 4 < pieces ? src[c + 4] : zero4;
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t q = c << 3;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       if (q + (uint32_t)i < n) {
@@ -702,6 +748,12 @@ coder_status_kernel (const lh264_code_stream_t* __restrict__ streams, const uint
     if (hc == 0u || (hc & (hc - 1u)) != 0u || hc > (1u << 20)) st |= LH264_CODER_ST_TABLE_FULL;      // a decision word carries 20 bits of table slot
     lens[LH264_N_TAG_SLOTS] = st;
     for (int t = 35; t < LH264_N_TAG_SLOTS; t++) lens[t] = 0;                                        // tag slots that do not exist
+#ifdef LH264_CODER_DEBUG
+    lens[36] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 90]; lens[37] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 91];
+    lens[38] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_NDEC];
+    lens[35] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 92]; lens[39] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 93];
+    lens[36] = lens[36] | chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 94] << 16; lens[37] = lens[37] | chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 95] << 20;
+#endif
   }
 }
 
