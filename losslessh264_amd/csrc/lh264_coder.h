@@ -19,7 +19,9 @@
 #define LH264_CODER_INFO_WORDS   96
 
 // threads of a coder_resolve_kernel workgroup (one workgroup per stream)
+#ifndef LH264_CODER_RESOLVE_WAVES
 #define LH264_CODER_RESOLVE_WAVES 8
+#endif
 #define LH264_CODER_RESOLVE_THREADS (64 * LH264_CODER_RESOLVE_WAVES)
 
 // status bits reported in out_len_dev[LH264_N_TAG_SLOTS]

@@ -169,6 +169,72 @@ template <class S> __device__ __forceinline__ void binarize (S& s, uint32_t prio
   }
 }
 
+// ---- how many decisions a symbol becomes, per tag, without walking its binarisation (same cases as binarize above) -------------
+struct SymCount { int n, s0, s1, s2, s3, n0, n1, n2, n3, tch; };      // at most four tags (slots; -1: unused), tch: tag brought into existence
+// the tail of emitInt behind its zero flag / sign: exponent (unary) and mantissa decisions of data >= 1 (after the sign)
+__device__ __forceinline__ void cnt_int_tail (int data, int order, int& ne, int& nm) {
+  data--;
+  const int l2 = 31 - __clz (1 + (data >> order));
+  ne += l2 + 1; nm += l2 + order;
+}
+__device__ __forceinline__ SymCount sym_count (uint32_t prior, int value, int kind, int pad) {
+  enum { T_LDC = 17, T_CRDC = 18, T_LAC_0_EOB = 19, T_LAC_N_EOB = 24, T_CRAC_EOB = 29 };
+  SymCount c; c.n = 0; c.s0 = c.s1 = c.s2 = c.s3 = -1; c.n0 = c.n1 = c.n2 = c.n3 = 0; c.tch = -1;
+  const int table = (int) (prior >> 27);
+  switch (kind) {
+  case LH264_SYM_LUMA_DC: case LH264_SYM_CHROMA_DC: case LH264_SYM_NZ4: case LH264_SYM_NZ8: {
+    const bool dc = kind == LH264_SYM_LUMA_DC || kind == LH264_SYM_CHROMA_DC;
+    const int t = kind == LH264_SYM_LUMA_DC ? T_LDC : kind == LH264_SYM_CHROMA_DC ? T_CRDC : (((prior / 27u) % 3u) ? T_CRAC_EOB : T_LAC_0_EOB);
+    int n = 1, ne = 0, nm = 0;                                   // the zero flag
+    if (value != 0) { if (dc) n++; cnt_int_tail (value < 0 ? -value : value, 0, ne, nm); }      // sign (DC only), exponent, mantissa
+    c.n = n + ne + nm; c.s0 = t; c.n0 = c.n;
+    break; }
+  case LH264_SYM_AC4: case LH264_SYM_AC8: {
+    const uint32_t nco = kind == LH264_SYM_AC4 ? 16u : 64u;
+    const uint32_t outer = prior / 3125u;
+    const int emitted = (int) (outer % nco), color = (int) ((outer / nco) % 3u), code = (int) ((outer / nco / 3u) % 16u);
+    const int first = color == 0 && emitted == 0 && code != 1;
+    const int base = color ? T_CRAC_EOB : (first ? T_LAC_0_EOB : T_LAC_N_EOB);
+    c.tch = base + 2;
+    int nz = 1, ns = 0, ne = 0, nm = 0;
+    if (value != 0) {
+      ns = 1;
+      const int u = (value < 0 ? -value : value) - 1;
+      nm = u >= 14 ? 14 : u + 1;
+      if (u >= 14) { nz++; if (u - 14 != 0) cnt_int_tail (u - 14, 0, ne, nm); }
+    }
+    c.n = nz + ns + ne + nm;
+    c.s0 = base + 1; c.n0 = nz;
+    if (ns) { c.s1 = base + 4; c.n1 = ns; }
+    if (nm) { c.s2 = base + 3; c.n2 = nm; }
+    if (ne) { c.s3 = base + 2; c.n3 = ne; }
+    break; }
+  case LH264_SYM_BIT: c.n = 1; break;
+  case LH264_SYM_RAW: c.n = (int)prior > 0 ? (int)prior : 0; break;
+  case LH264_SYM_MVD: {                                         // UEGk<9,4,3,4,3>
+    int n = 1, ne = 0, nm = 0;
+    if (value != 0) {
+      n++;
+      const int u = (value < 0 ? -value : value) - 1;
+      nm = u >= 9 ? 9 : u + 1;
+      if (u >= 9) { n++; if (u - 9 != 0) cnt_int_tail (u - 9, 3, ne, nm); }
+    }
+    c.n = n + ne + nm;
+    break; }
+  case LH264_SYM_TREE: c.n = table == LH264_TB_SKIPRUN ? 9 : table == LH264_TB_SUBMB ? 8 : table == LH264_TB_CBPC ? 2 : 4; break;
+  case LH264_SYM_POW2: {
+    const bool qpl = table == LH264_TB_QPL;
+    const unsigned preferred = qpl ? 0u : (prior & 0x7ffffffu), data = (unsigned) (uint16_t)value;
+    c.n = 1 + (data != preferred ? (qpl ? 7 : 3) : 0);
+    break; }
+  default: break;
+  }
+  if (kind >= LH264_SYM_TREE && c.n > 0) { c.s0 = tag_slot (pad); c.n0 = c.n; }      // the host's symbols name their tag
+  else { if (c.s0 >= 0) c.s0 = tag_slot (c.s0); if (c.s1 >= 0) c.s1 = tag_slot (c.s1); if (c.s2 >= 0) c.s2 = tag_slot (c.s2); if (c.s3 >= 0) c.s3 = tag_slot (c.s3); }
+  if (c.tch >= 0) c.tch = tag_slot (c.tch);
+  return c;
+}
+
 // ---- the symbols of one macroblock in coding order: the host list with the coefficient symbols in place of the marker ---------
 struct MbSyms {
   const GLB uint64_t* hs; const GLB uint64_t* cs;
@@ -177,7 +243,8 @@ struct MbSyms {
 __device__ __forceinline__ MbSyms mb_syms (const lh264_code_job_t* J, int k, int lane) {
   MbSyms m;
   const GLB uint32_t* off = glb<const uint32_t> (J->syn_off_dev);
-  const uint32_t o0 = (uint32_t)uniform ((int)off[k]), o1 = (uint32_t)uniform ((int)off[k + 1]);
+  const uint32_t o0v = off[k], o1v = off[k + 1], mcv = glb<const uint16_t> (J->ctx_n_syms_dev)[k];       // one round trip for the three
+  const uint32_t o0 = (uint32_t)uniform ((int)o0v), o1 = (uint32_t)uniform ((int)o1v);
   const int nh = (int) (o1 - o0);
   m.hs = glb<const uint64_t> (J->syn_syms_dev) + o0;
   m.cs = glb<const uint64_t> (J->ctx_syms_dev) + (size_t)k * LH264_CTX_MAX_SYMS;
@@ -187,7 +254,7 @@ __device__ __forceinline__ MbSyms mb_syms (const lh264_code_job_t* J, int k, int
     const unsigned long long spl = __ballot (c + lane < nh && ((hv >> 48) & 0xffull) == (unsigned long long)LH264_SYM_SPLICE);
     if (spl) { m.p = c + __ffsll ((long long)spl) - 1; m.hskip = 1; break; }
   }
-  if (m.hskip) m.mc = uniform ((int)glb<const uint16_t> (J->ctx_n_syms_dev)[k]);
+  if (m.hskip) m.mc = uniform ((int)mcv);
   m.total = nh - m.hskip + m.mc;
   return m;
 }
@@ -198,25 +265,6 @@ __device__ __forceinline__ uint64_t mb_sym_at (const MbSyms& m, int i) {
 }
 
 // ---- sinks -----------------------------------------------------------------------------------------------------------------
-struct TotalSink {
-  int n;
-  __device__ __forceinline__ void cell (uint32_t) {}
-  __device__ __forceinline__ void touch (int) {}
-  __device__ __forceinline__ void dec (int, int, int) { n++; }
-};
-// a symbol's decisions go to at most four tags
-struct CountSink {
-  int n, s0, s1, s2, s3, n0, n1, n2, n3, tch; bool many;
-  __device__ __forceinline__ void cell (uint32_t) {}
-  __device__ __forceinline__ void touch (int tag) { tch = tag_slot (tag); }
-  __device__ __forceinline__ void dec (int, int, int tag) {
-    const int sl = tag_slot (tag);
-    n++;
-    if (sl == s0) n0++; else if (sl == s1) n1++; else if (sl == s2) n2++; else if (sl == s3) n3++;
-    else if (s0 < 0) { s0 = sl; n0 = 1; } else if (s1 < 0) { s1 = sl; n1 = 1; } else if (s2 < 0) { s2 = sl; n2 = 1; }
-    else if (s3 < 0) { s3 = sl; n3 = 1; } else many = true;
-  }
-};
 // a decision word (64 bits): the low dword is the key of the prior's cell (LH264_PRIOR form; 0 for a raw bit), the high dword
 // bits 0..3 the place in the cell, bit 4 the bit, bits 5..10 the tag slot, bit 31 "raw bit" (coded with TEST_PROB)
 struct EmitSink {
@@ -279,15 +327,13 @@ coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* _
       if (i < m.total) {
         const uint64_t sym = mb_sym_at (m, i);
         const uint32_t hi = (uint32_t) (sym >> 32);
-        CountSink s; s.n = 0; s.s0 = s.s1 = s.s2 = s.s3 = -1; s.n0 = s.n1 = s.n2 = s.n3 = 0; s.tch = -1; s.many = false;
-        binarize (s, (uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24));
+        const SymCount s = sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24));
         if (s.s0 >= 0) atomicAdd (&lc[wave][s.s0], (uint32_t)s.n0);
         if (s.s1 >= 0) atomicAdd (&lc[wave][s.s1], (uint32_t)s.n1);
         if (s.s2 >= 0) atomicAdd (&lc[wave][s.s2], (uint32_t)s.n2);
         if (s.s3 >= 0) atomicAdd (&lc[wave][s.s3], (uint32_t)s.n3);
         if (s.tch >= 0) atomicOr (&lc[wave][s.tch], 0x80000000u);
         atomicAdd (&lc[wave][LH264_N_TAG_SLOTS], (uint32_t)s.n);
-        bad = bad || s.many;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -314,12 +360,12 @@ coder_scan_kernel (const uint32_t* __restrict__ jobmb0, const int32_t* __restric
   const int t = lane <= LH264_N_TAG_SLOTS ? lane : LH264_N_TAG_SLOTS;
   const GLB uint16_t* p = glb<const uint16_t> (cnt) + t;
   size_t mb = m0;
-  for (; mb + 8 <= m1; mb += 8) {
-    uint32_t v[8];
+  for (; mb + 32 <= m1; mb += 32) {              // 32 reads in flight per lane: the walk is bound by memory latency
+    uint32_t v[32];
 #pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = p[(mb + i) * LH264_CODER_CNT_STRIDE];
+    for (int i = 0; i < 32; i++) v[i] = p[(mb + i) * LH264_CODER_CNT_STRIDE];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 32; i++) {
       if (lane == LH264_N_TAG_SLOTS) { doff[mb + i] = acc; acc += v[i]; }
       else { acc += v[i] & 0x7fffu; touched |= v[i] >> 15; }
     }
@@ -392,11 +438,11 @@ coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __
     for (int c = 0; c < m.total; c += 64) {
       const int i = c + lane;
       uint64_t sym = 0; uint32_t hi = 0;
-      TotalSink ts; ts.n = 0;
+      struct { int n; } ts; ts.n = 0;
       if (i < m.total) {
         sym = mb_sym_at (m, i);
         hi = (uint32_t) (sym >> 32);
-        binarize (ts, (uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24));
+        ts.n = sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24)).n;
       }
       const int incl = wave_scan_add (ts.n);
       if (i < m.total && ts.n > 0) {
@@ -427,16 +473,32 @@ __device__ __forceinline__ int below (uint32_t lo, uint32_t hi) { return (int)__
 // follows from the stored pair, and the halving is done by the next reader.  An entry of the LDS cache (and of the spill table in HBM) is
 // 64 bits: counters in bits 0..19, the DynProb's key (cell key << 4 | place, 36 bits) in bits 20..55, bit 63 set.  All zero = free.
 #define RS_WAVES LH264_CODER_RESOLVE_WAVES
-#define RS_SLOTS 8192            // DynProbs in the LDS cache
+// diagnostic build (-DLH264_CODER_DEBUG): shader-clock stamps of the resolve kernel's phases, summed over the waves of a stream into
+// chain_info words 90..94 (in units of 1024 cycles), reported in the unused length slots 35..39
+#ifdef LH264_CODER_DEBUG
+#define RS_STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define RS_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
+#define RS_STAMP_FLUSH if (lane == 0) for (int q_ = 0; q_ < 6; q_++) atomicAdd (&chain_info[(size_t)chain * LH264_CODER_INFO_WORDS + 90 + q_], (uint32_t) (st_acc[q_] >> 10));
+#else
+#define RS_STAMP_DECL
+#define RS_STAMP(i)
+#define RS_STAMP_FLUSH
+#endif
+#define RS_LOG2_BUCKETS 11
+#define RS_SLOTS (4 << RS_LOG2_BUCKETS)        // DynProbs in the LDS cache: 8192
 #define RS_CHECK 4               // the fill of the cache is looked at every RS_CHECK workgroup steps (that many steps insert <= 2048)
+#ifndef RS_FLUSH
 #define RS_FLUSH 4600            // everything goes to the spill table and the cache starts over above this many
+#endif
 struct ResolveLds {
   unsigned long long ent[RS_SLOTS];
   uint32_t cursor[LH264_N_TAG_SLOTS];
   uint32_t test_prob;            // TEST_PROB: the DynProb shared by the raw bits of all tags
   uint32_t ticket;               // the next wave step allowed into the serial section
   uint32_t nres;                 // entries in the cache
+  uint32_t flush_step;           // the last workgroup step at whose end the cache is (was) flushed
   uint32_t scratch[RS_WAVES][64];
+  uint32_t ring[RS_WAVES][3][2][64];       // per wave: the decision words of three future rounds (low dwords, high dwords), filled by LDS-DMA
 };
 __device__ __forceinline__ unsigned long long rs_key (uint32_t lo, uint32_t hi) { return (unsigned long long)lo << 4 | (unsigned long long) (hi & 15u); }
 #define RS_ENT_KEY(e) (((e) >> 20) & 0xfffffffffull)
@@ -449,9 +511,9 @@ __device__ __forceinline__ void spill_put (GLB unsigned long long* T, uint32_t t
   const unsigned long long val = RS_ENT_MAKE (key, st);
   uint32_t h = rs_hash (key) >> 8;
   for (uint32_t tries = 0; tries <= tmask; tries++, h++) {
-    unsigned long long* p = (unsigned long long*) (uintptr_t) (T + (h & tmask));
+    GLB unsigned long long* p = T + (h & tmask);
     unsigned long long cur = __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == 0ull) { cur = atomicCAS (p, 0ull, val); if (cur == 0ull) return; }
+    if (cur == 0ull) { unsigned long long expect = 0ull; if (__hip_atomic_compare_exchange_strong (p, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; cur = expect; }
     if (RS_ENT_KEY (cur) == key) { __hip_atomic_store (p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }      // (a key sits in one cache entry: nobody else writes it now)
   }
 }
@@ -462,7 +524,7 @@ __device__ __forceinline__ uint32_t spill_get (const GLB unsigned long long* T, 
     if (cur == 0ull) return 0u;
     if (RS_ENT_KEY (cur) == key) return (uint32_t)cur & 0xfffffu;
     h++;
-    cur = __hip_atomic_load ((unsigned long long*) (uintptr_t) (T + (h & tmask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cur = __hip_atomic_load (T + (h & tmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   return 0u;
 }
@@ -474,22 +536,32 @@ __device__ __forceinline__ void rs_lookup (LDS ResolveLds& S, const GLB unsigned
   R.idx = 0; R.miss = false; R.inserted = false; R.first = 0ull;
   if (valid && !(hi & 0x80000000u)) {
     const unsigned long long key = rs_key (lo, hi), fresh = RS_ENT_MAKE (key, 0u);
-    uint32_t h = rs_hash (key) >> 19;
-    for (int tries = 0; tries < 2 * RS_SLOTS; tries++) {      // (the flush policy keeps the cache at most 7/8 full: bounded anyway)
-      h &= RS_SLOTS - 1;
-      unsigned long long cur = * (volatile LDS unsigned long long*)&S.ent[h];
-      if (cur == 0ull) {
+    // buckets of four entries (32 bytes, read at once): a probe looks at a whole bucket, so the longest probe sequence among the 64
+    // lanes of a wave - which is what the wave waits for - stays short
+    uint32_t bkt = rs_hash (key) >> (32 - RS_LOG2_BUCKETS), h = 0;
+    for (int tries = 0; tries < RS_SLOTS / 4; tries++, bkt++) {      // (the flush policy keeps the cache at most 7/8 full: bounded anyway)
+      bkt &= RS_SLOTS / 4 - 1;
+      const LDS u32x4* bp = (const LDS u32x4*)&S.ent[4u * bkt];
+      const u32x4 a = * (volatile const LDS u32x4*)bp, b = * (volatile const LDS u32x4*) (bp + 1);
+      const unsigned long long e[4] = {(unsigned long long)a.x | (unsigned long long)a.y << 32, (unsigned long long)a.z | (unsigned long long)a.w << 32,
+                                       (unsigned long long)b.x | (unsigned long long)b.y << 32, (unsigned long long)b.z | (unsigned long long)b.w << 32};
+      int found = -1, empty = -1;
+#pragma unroll
+      for (int q = 3; q >= 0; q--) { if (e[q] == 0ull) empty = q; if (e[q] != 0ull && RS_ENT_KEY (e[q]) == key) found = q; }
+      if (found >= 0) { h = 4u * bkt + (uint32_t)found; break; }
+      if (empty >= 0) {
+        // take the first free entry of the bucket; if another lane is quicker, look at the bucket again (it may have put this very key there)
         unsigned long long expect = 0ull;
-        if (__hip_atomic_compare_exchange_strong (&S.ent[h], &expect, fresh, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { R.miss = true; break; }
-        cur = expect;
+        if (__hip_atomic_compare_exchange_strong (&S.ent[4u * bkt + (uint32_t)empty], &expect, fresh, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          h = 4u * bkt + (uint32_t)empty; R.miss = true; break;
+        }
+        bkt--;
       }
-      if (RS_ENT_KEY (cur) == key) break;
-      h++;
     }
     R.idx = (int)h;
     R.inserted = R.miss;
     R.miss = R.miss && spilled;                                // before the first flush a new DynProb is simply fresh
-    if (R.miss) R.first = __hip_atomic_load ((unsigned long long*) (uintptr_t) (T + ((rs_hash (key) >> 8) & tmask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (R.miss) R.first = __hip_atomic_load (T + ((rs_hash (key) >> 8) & tmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 // the counters the spill table holds for an entry inserted by rs_lookup go into the entry (it has not been used yet)
@@ -533,25 +605,60 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
   const uint32_t tmask = streams[chain].hash_cap * 8u - 1u;            // hash_cap cells of 64 bytes = 8 entries each
   for (int i = tid; i < RS_SLOTS; i += RS_WAVES * 64) S.ent[i] = 0ull;
   if (tid < LH264_N_TAG_SLOTS) S.cursor[tid] = I[LH264_CODER_INFO_TAGBASE + tid];
-  if (tid == 0) { S.test_prob = 0; S.ticket = 0; S.nres = 0; }
+  if (tid == 0) { S.test_prob = 0; S.ticket = 0; S.nres = 0; S.flush_step = 0xffffffffu; }
   __syncthreads();
   const uint32_t n_rounds = (n + 63u) >> 6;
   const uint32_t n_iter = (n_rounds + RS_WAVES - 1) / RS_WAVES;
   uint32_t r = (uint32_t)wave;
   auto fetch = [&] (uint32_t round) -> uint64_t { const uint32_t i = round * 64u + (uint32_t)lane; return i < n ? Dc[i] : 0ull; };
   auto is_valid = [&] (uint32_t round) -> bool { return round * 64u + (uint32_t)lane < n; };
-  // rounds r (resolved in this step), r + W (looked up; a spilled answer is taken in this step), r + 2W (looked up in this step), then the words
+  // Decision words travel HBM -> LDS by LDS-DMA, three workgroup steps ahead of their use, so that neither the compiler's nor
+  // this code's waits for OTHER memory operations ever have to wait for a word that was only just requested.  (Always issued - the
+  // index is clamped - so that the counted wait below is right in the last steps too.)
+  const uint32_t my_ring = (uint32_t) (uintptr_t)&S.ring[wave][0][0][0];
+  auto dma = [&] (uint32_t round, uint32_t slot) {
+    uint32_t i = round * 64u + (uint32_t)lane;
+    if (i >= n) i = n - 1u;
+    const GLB uint32_t* src = (const GLB uint32_t*) (Dc + i);
+    // (as asm statements: hipcc would make every later LDS read wait for a load it knows to write LDS; M0 = the LDS address of lane 0's
+    // dword, saved and restored inside the statement)
+    const uint32_t dst = (uint32_t)uniform ((int) (my_ring + slot * 512u));
+    uint32_t keep;
+    asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                  : "=&s"(keep) : "v"(src), "v"(src + 1), "s"(dst), "s"(dst + 256u) : "memory");
+  };
+  if (n == 0u) return;
+  // rounds r (resolved in this step), r + W (looked up; a spilled answer is taken in this step), r + 2W (looked up in this step)
   uint64_t w0 = fetch (r), w1 = fetch (r + RS_WAVES), w2 = fetch (r + 2 * RS_WAVES);
-  uint64_t q0 = fetch (r + 3 * RS_WAVES), q1 = fetch (r + 4 * RS_WAVES), q2 = fetch (r + 5 * RS_WAVES);
+  dma (r + 3 * RS_WAVES, 0u); dma (r + 4 * RS_WAVES, 1u); dma (r + 5 * RS_WAVES, 2u);
   bool spilled = false;
   SlotRef e0, e1;
   rs_lookup (S, T, tmask, (uint32_t)w0, (uint32_t) (w0 >> 32), is_valid (r), false, e0);
   rs_lookup (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), is_valid (r + RS_WAVES), false, e1);
   rs_count (S, e0.inserted, lane); rs_count (S, e1.inserted, lane);
   __syncthreads();
+  RS_STAMP_DECL
+  bool pend_ok = false; uint32_t pend_q = 0, pend_v = 0;
   for (uint32_t it = 0; it < n_iter; it++) {
     const bool v_cur = is_valid (r), round_ok = r < n_rounds;
+    // every RS_CHECK steps, and only while every wave of the step has a round
+    const bool check = (it % RS_CHECK) == RS_CHECK - 1 && (it + 1u) * RS_WAVES <= n_rounds;
+    bool do_flush = false;
+    if (pend_ok) Qc[pend_q] = (uint16_t)pend_v;          // the list entry of the round resolved in the last step
+    pend_ok = false;
     const uint32_t w_hi = (uint32_t) (w0 >> 32);
+    // the words of round r + 3W: requested three steps ago; the four requests behind them may still be under way
+    asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
+    const uint32_t slot = it % 3u;
+    const uint64_t w3 = (uint64_t) * (volatile LDS uint32_t*) (uintptr_t) (my_ring + slot * 512u + (uint32_t)lane * 4u) |
+                        (uint64_t) * (volatile LDS uint32_t*) (uintptr_t) (my_ring + slot * 512u + 256u + (uint32_t)lane * 4u) << 32;
+    RS_STAMP (5)
+    // ---- the entries of the round two steps ahead, first thing: spilled counters that are requested here are taken a whole step later
+    // (inserting does not disturb the rounds in flight: they use entries they found earlier) ----------------------------------------------
+    SlotRef e2;
+    rs_lookup (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), is_valid (r + 2 * RS_WAVES), spilled, e2);
+    rs_count (S, e2.inserted, lane);
+    RS_STAMP (4)
     // ---- what does not depend on the adaptive state: who shares my DynProb, who shares my tag ----------------------------------------
     const bool raw = (w_hi & 0x80000000u) != 0;
     const int bit = (int) ((w_hi >> 4) & 1u), tag = (int) ((w_hi >> 5) & 63u);
@@ -567,6 +674,7 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
     const int head = slo ? __ffs ((int)slo) - 1 : 32 + __ffs ((int)shi) - 1;
     // spilled counters requested a step ago: into the entries now (before this wave's turn, see above)
     rs_land (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), e1);
+    RS_STAMP (0)
     // ---- the serial section: counters in, counters out -------------------------------------------------------------------------------
     if (round_ok) {
       volatile LDS uint32_t* sp = raw ? &S.test_prob : (volatile LDS uint32_t*)&S.ent[e0.idx];
@@ -577,9 +685,18 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
         for (; *tk != r && spins < (1u << 16); spins++) __builtin_amdgcn_s_sleep (0);
         if (spins >= (1u << 16) && lane == 0) atomicOr (&chain_info[(size_t)chain * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_HANDOFF);
       }
-      asm volatile ("" ::: "memory");
       uint32_t st = 0, cb = 0;
       if (v_cur) { st = *sp; cb = *cp; }
+      __builtin_amdgcn_s_setprio (3);                // the waves behind this one are waiting for exactly this section
+      asm volatile ("" ::: "memory");
+      RS_STAMP (1)
+      if (check) {
+        // is the cache filling up?  The first wave of the step decides inside its turn, the others read the decision inside theirs
+        // (later in ticket order): no barrier unless there is something to flush
+        volatile LDS uint32_t* fs = &S.flush_step;
+        if (wave == 0 && * (volatile LDS uint32_t*)&S.nres > RS_FLUSH) *fs = it;
+        do_flush = *fs == it;
+      }
       const uint32_t c0 = st & 1023u, c1 = (st >> 10) & 1023u;
       const bool lazy = c0 + c1 > 512u;                                     // the halving the last decision left to its successor
       const uint32_t f0 = lazy ? (c0 + 1u) >> 1 : c0, f1 = lazy ? (c1 + 1u) >> 1 : c1;
@@ -606,20 +723,17 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
       asm volatile ("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) { volatile LDS uint32_t* tk = &S.ticket; *tk = r + 1u; }
+      __builtin_amdgcn_s_setprio (0);
+      RS_STAMP (2)
       // ---- afterwards: the probability, and the entry of the tag's list ------------------------------------------------------------------
+      // (stored at the top of the next step: a store as the youngest memory operation at the loop's end would make the compiler's
+      // wait for the spill-table answers wait for the store as well)
       const uint32_t prob = dp_ratio (a0, a1);
-      if (v_cur) Qc[cb + (uint32_t)trank] = (uint16_t) (prob << 1 | (uint32_t)bit);
+      pend_ok = v_cur; pend_q = cb + (uint32_t)trank; pend_v = prob << 1 | (uint32_t)bit;
     }
-    // ---- the entries of the round two steps ahead (inserting does not disturb the rounds in flight: they use entries they found earlier) --
-    SlotRef e2;
-    rs_lookup (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), is_valid (r + 2 * RS_WAVES), spilled, e2);
-    rs_count (S, e2.inserted, lane);
-    if ((it % RS_CHECK) == RS_CHECK - 1) {
-      // ---- every few steps: is the cache filling up? ----------------------------------------------------------------------------------
-      rs_barrier();
-      const uint32_t resident = * (volatile LDS uint32_t*)&S.nres;
-      rs_barrier();
-      if (resident > RS_FLUSH) {
+    RS_STAMP (3)
+    {
+      if (do_flush) {
         // every DynProb to the spill table, then the cache starts over with the entries of the two rounds in flight
         rs_land (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), e1);
         rs_land (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), e2);
@@ -640,10 +754,14 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
         rs_barrier();
       }
     }
+    asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ring slot has been read: it takes the words of round r + 6W
+    dma (r + 6 * RS_WAVES, slot);
     r += RS_WAVES;
-    w0 = w1; w1 = w2; w2 = q0; q0 = q1; q1 = q2; q2 = fetch (r + 5 * RS_WAVES);
+    w0 = w1; w1 = w2; w2 = is_valid (r + 2 * RS_WAVES) ? w3 : 0ull;
     e0 = e1; e1 = e2;
   }
+  if (pend_ok) Qc[pend_q] = (uint16_t)pend_v;
+  RS_STAMP_FLUSH
 }
 
 // ---- kernel 6: per (stream, tag) the libvpx bool coder (vpx_writer, bitwriter.h:35-105) with the carry resolved in registers -----
@@ -670,7 +788,7 @@ __device__ __forceinline__ void bc_byte (Bc& b, GLB uint8_t* out, uint32_t cap, 
   }
 }
 __device__ __forceinline__ void bc_write (Bc& b, GLB uint8_t* out, uint32_t cap, int bit, int prob) {      // vpx_write
-  const uint32_t split = 1u + (((b.range - 1u) * (uint32_t)prob) >> 8);
+  const uint32_t split = 1u + (__umul24 (b.range - 1u, (uint32_t)prob) >> 8);          // both factors < 256
   uint32_t range = split, low = b.low;
   if (bit) { low += split; range = b.range - split; }
   int shift = range < 128u ? __clz ((int)range) - 24 : 0;          // vpx_norm[range]
@@ -723,11 +841,19 @@ coder_code_kernel (const lh264_code_stream_t* __restrict__ streams, const uint32
     p0 = p1; p1 = p2; p2 = p3; p3 = c + 4 < pieces ? src[c + 4] : zero4;
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
     const uint32_t q = c << 3;
+    if (q + 8u <= n) {                    // a whole piece: no per-decision test
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      if (q + (uint32_t)i < n) {
+      for (int i = 0; i < 8; i++) {
         const uint32_t e = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
         bc_write (bc, o, cap, (int) (e & 1u), (int) (e >> 1));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (q + (uint32_t)i < n) {
+          const uint32_t e = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+          bc_write (bc, o, cap, (int) (e & 1u), (int) (e >> 1));
+        }
       }
     }
   }
@@ -749,10 +875,8 @@ coder_status_kernel (const lh264_code_stream_t* __restrict__ streams, const uint
     lens[LH264_N_TAG_SLOTS] = st;
     for (int t = 35; t < LH264_N_TAG_SLOTS; t++) lens[t] = 0;                                        // tag slots that do not exist
 #ifdef LH264_CODER_DEBUG
-    lens[36] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 90]; lens[37] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 91];
-    lens[38] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_NDEC];
-    lens[35] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 92]; lens[39] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 93];
-    lens[36] = lens[36] | chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 94] << 16; lens[37] = lens[37] | chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 95] << 20;
+    for (int q = 0; q < 5; q++) lens[35 + q] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 90 + q];
+    lens[34] = chain_info[(size_t)c * LH264_CODER_INFO_WORDS + 95];
 #endif
   }
 }

@@ -17,6 +17,7 @@ for name in sys.argv[1:] or ["BA_MW_D.264"]:
     used = keys != 0
     print(name, "frames", len(frames), "mbs", sum(f.mb_w * f.mb_h for f in frames), "distinct cells", int(used.sum()),
           "distinct DynProbs (nonzero state)", int((cells != 0).sum()), flush=True)
-    lens = coder.d_len[:41].cpu().numpy()
-    print("   debug build only: flushes", int(lens[36]) & 0xffff, "misses", int(lens[37]) & 0xfffff, "decisions", int(lens[38]),
-          "timeouts", int(lens[35]), "first: round", int(lens[39]), "ticket seen", int(lens[36]) >> 16, "step", int(lens[37]) >> 20, "status", int(lens[40]), flush=True)
+    lens = coder.d_len[:41].cpu().numpy().astype(np.int64)
+    names = ["pre-work + land", "ticket wait", "serial section", "probability + store", "lookup two steps ahead"]
+    tot = max(1, int(lens[35:40].sum()))
+    print("   debug build only (wave time, k-cycles):", ", ".join("%s %d (%.0f%%)" % (names[i], lens[35 + i], 100.0 * lens[35 + i] / tot) for i in range(5)), "status", int(lens[40]), flush=True)
