@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py - one "step" = one pass of the hot path (inverse transforms,
-intra/inter prediction, in-loop deblocking, reference padding, and the recompressor's per-coefficient context-model
-prior lookup) over one batch of independent streams resident in HBM.
+"""bench.py - one "step" = one pass of the whole device-side compress direction over one batch
+of independent streams resident in HBM: inverse transforms, intra/inter prediction, in-loop deblocking and reference padding
+(a1-a7, `recon_chain_kernel`), the recompressor's per-coefficient context-model prior lookup (a8, the ctx_* kernels) and the adaptive
+binary arithmetic coder that produces the compressed bytes (a9/a10, the coder_* kernels).  `value` counts a stream as recompressed
+only when its tagged byte streams exist in HBM.
 
-Workload at N=1 = BASELINE.json configs[1]: the res/ Baseline CAVLC conformance stream BA_MW_D.264
-(QCIF, 100 frames, 55,885 B) replicated as 512 independent streams per GPU (each replica owns its records
-and pictures in HBM).  The stream is parsed by the product's own host front end; the records the reference's
-parser produced for it (tests/golden/bench_BA_MW_D.264.npz) serve the parity spot check.  N>1: every rank processes
-its own 512 streams (weak scaling, no data-path collective; only the timing barrier/max uses RCCL).
+Workloads (BASELINE.json configs; `--config`, default 1 = the configuration the metric is quoted on):
+  1  res/BA_MW_D.264 (Baseline CAVLC, QCIF, 100 frames) x 512 independent streams per GPU
+  2  1280x720 all-intra CAVLC, 4 slices per picture (the SURVEY's synthetic pattern through the reference's encoder) x 1024
+  3  1920x1080 I/P Baseline (same generator, -iper 16), the largest batch one GPU holds comfortably
+  4  the CABAC path: roundtriptest/tibbycabac.264 + res/test_cif_P_CABAC_slice.264 alternating, 1024 streams
+Every replica owns its records and pictures in HBM.  The streams are parsed by the product's own host front end.
 
-Prints ONE JSON line (see the contract in the task description).
+N > 1 (`--gpus N`): one process per GPU.  Under torchrun the ranks exist already; otherwise this script starts them itself (fresh
+processes, before anything touches a GPU).  The global stream list (N x the per-GPU batch) is cut by macroblock count
+(losslessh264_amd/shard.py), every rank compresses its share, the per-stream result records are gathered over RCCL and checked
+once on rank 0.  Weak scaling; no data-path collective.
+
+Prints ONE JSON line (the contract in the task description).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,22 +34,50 @@ INTRA_BYTES_PER_MB = 1280      # 768 coeff + 128 record read, 384 written       
 INTER_BYTES_PER_MB = 1883      # + 603 reference samples for a 16x16 partition       
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
+CONFIGS = {
+    1: {"what": "configs[1]: res/BA_MW_D.264 (QCIF, 100 frames) x %d independent streams per GPU", "streams": ["BA_MW_D.264"], "n": 512, "frames": None},
+    2: {"what": "configs[2]: 1280x720 all-intra CAVLC, 4 slices per picture (synthetic pattern, reference encoder, QP 26), %d frames x %d streams per GPU",
+        "streams": ["syn720p_allI_4slices_8f.264"], "n": 1024, "frames": 4},
+    3: {"what": "configs[3]: 1920x1080 I/P Baseline (synthetic pattern, reference encoder, -iper 16), %d frames x %d streams per GPU",
+        "streams": ["syn1080p_IP_8f.264"], "n": 256, "frames": 8},
+    4: {"what": "configs[4]: CABAC path, roundtriptest/tibbycabac.264 + res/test_cif_P_CABAC_slice.264 alternating, first %d frames x %d streams per GPU",
+        "streams": ["tibbycabac.264", "test_cif_P_CABAC_slice.264"], "n": 1024, "frames": 24},
+}
 
-def cpu_baseline(frames, stream_bytes, seconds):
-    """the oracle (our C restatement of the reference path, oracle/) on ONE host core, bounded sample"""
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: N fresh child processes (this one never touches a GPU), rank 0's line is ours"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    sys.stdout.write(out)
+    sys.exit(rc)
+
+
+def cpu_pass_factory(frames):
+    """one pass of the oracle (our C restatement of the reference path, rows a1-a8) over a stream; thread-safe (own buffers)"""
     import ctypes as C
+    import numpy as np
     import oracle_lib as O
     from losslessh264_amd.ctx import past_policy
     L = O.lib()
     L.orc_model_frame_symbols.restype = C.c_long
     pol = past_policy(frames)
     nmax = max(f.mb_w * f.mb_h for f in frames)
-    syms = np.zeros(nmax * 432, dtype=O.ORC_SYM_DTYPE)
-    nsy = np.zeros(nmax, dtype=np.uint16)
     prep = [(np.ascontiguousarray(f.mbs), np.ascontiguousarray(f.slices), np.ascontiguousarray(f.levels, dtype=np.int16)) for f in frames]
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
+
+    def one_pass():
+        syms = np.zeros(nmax * 432, dtype=O.ORC_SYM_DTYPE)
+        nsy = np.zeros(nmax, dtype=np.uint16)
         pics, imgs = {}, []
         for i, f in enumerate(frames):
             dst = O.HostPic(f.mb_w, f.mb_h)
@@ -58,19 +93,32 @@ def cpu_baseline(frames, stream_bytes, seconds):
                                       past.ctypes.data_as(C.c_void_p) if past is not None else None,
                                       syms.ctypes.data_as(C.c_void_p), nsy.ctypes.data_as(C.c_void_p))
             imgs.append(img)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds:
-            break
+    return one_pass
+
+
+def cpu_baseline(frames, stream_bytes, seconds, threads):
+    """the oracle on `threads` host threads (one stream each, as SURVEY 8d asks: P = min(cores, streams)); bounded sample"""
+    from concurrent.futures import ThreadPoolExecutor
+    one = cpu_pass_factory(frames)
+    one()                                                  # builds the oracle library on first use
+    t0 = time.perf_counter()
+
+    def worker(_):
+        n = 0
+        while time.perf_counter() - t0 < seconds:
+            one(); n += 1
+        return n
+    with ThreadPoolExecutor(threads) as ex:
+        reps = sum(ex.map(worker, range(threads)))
+    dt = time.perf_counter() - t0
     return reps * stream_bytes / dt / 1e6, reps, dt
 
 
-def reference_cli_baseline(stream, stream_bytes):
+def reference_cli_baseline(stream, stream_bytes, procs):
     """the unmodified reference's console application (oracle/_ref/h264dec, built in the build container by oracle/Makefile and
-    shipped like our own .so) compressing the bench stream once on this box: its whole pipeline (parse + reconstruct + model +
-    coder), one core.  In-call time from its own 'decode time' line; the wall time includes ~10 s of start-up (8.8 GB of tables)."""
+    shipped like our own .so) compressing the stream on this box: its whole pipeline (parse + reconstruct + model + coder), one core per
+    process, `procs` processes at once (each allocates 8.8 GiB of prior tables).  In-call time from its own 'decode time' line."""
     import re
-    import subprocess
     import tempfile
     exe = os.path.join(ROOT, "oracle", "_ref", "h264dec")
     if not os.path.exists(exe):
@@ -78,15 +126,20 @@ def reference_cli_baseline(stream, stream_bytes):
     try:
         with tempfile.TemporaryDirectory() as d:
             t0 = time.perf_counter()
-            r = subprocess.run([exe, stream, os.path.join(d, "o.pip")], cwd=d, capture_output=True, timeout=240)
+            ps = []
+            for i in range(procs):
+                wd = os.path.join(d, str(i)); os.makedirs(wd)
+                ps.append(subprocess.Popen([exe, stream, os.path.join(wd, "o.pip")], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+            outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in ps]
             wall = time.perf_counter() - t0
-            m = re.search(r"decode time:\s*([0-9.]+) sec", r.stdout.decode(errors="replace") + r.stderr.decode(errors="replace"))
-            size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("o.pip"))
-        if r.returncode != 0 or not m:
+            secs = [float(m.group(1)) for m in (re.search(r"decode time:\s*([0-9.]+) sec", o) for o in outs) if m]
+            size = sum(os.path.getsize(os.path.join(d, "0", f)) for f in os.listdir(os.path.join(d, "0")) if f.startswith("o.pip"))
+        if len(secs) != procs or any(p.returncode != 0 for p in ps):
             return None
-        sec = float(m.group(1))
-        return {"value": stream_bytes / sec / 1e6, "unit": "MB/s", "cores": 1, "kind": "reference",
-                "sample": "oracle/_ref/h264dec BA_MW_D.264 -> .pip once: whole pipeline, in-call %.3f s (wall %.1f s with start-up), %d bytes written" % (sec, wall, size)}
+        return {"value": sum(stream_bytes / s for s in secs) / 1e6, "unit": "MB/s", "cores": procs, "kind": "reference",
+                "sample": "oracle/_ref/h264dec %s -> .pip, %d processes at once (one core each): whole pipeline, in-call %.3f s each on average "
+                          "(wall %.1f s with the start-up of the 8.8 GiB tables), %d bytes written per stream" % (
+                              os.path.basename(stream), procs, sum(secs) / procs, wall, size)}
     except Exception:
         return None
 
@@ -94,21 +147,30 @@ def reference_cli_baseline(stream, stream_bytes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=512, help="independent streams per GPU")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
+    ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (0: the config's batch)")
+    ap.add_argument("--frames", type=int, default=0, help="pictures per stream (0: the config's)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-coder", action="store_true", help="skip the separately timed arithmetic-coder stage")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-stage (front end / restore / end-to-end) measurements")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                   # does not return
 
+    import numpy as np
     import torch
     import golden_io
     import losslessh264_amd as lh
+    from losslessh264_amd import _lib as L
+    from losslessh264_amd import shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: running %d rank(s)\n" % (args.gpus, world, world))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -117,22 +179,57 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    # the stream goes through the product's own host front end (records + row-a10 syntax symbols); the records of the
-    # reference's parser (fixture) are only used for the parity spot check below
-    ref_frames = golden_io.load("bench_BA_MW_D.264")
-    data = open(os.path.join(ROOT, "tests", "golden", "streams", "BA_MW_D.264"), "rb").read()
-    stream_bytes = len(data)
-    assert stream_bytes == golden_io.load.stream_bytes
-    frames, perr, main_stream = lh.parse_file(data)     # main_stream: the recompressor's default stream (the .pip file itself)
-    assert perr == "" and len(frames) == len(ref_frames)
-    for f, g in zip(frames, ref_frames):
-        f.crc_fin, f.syms = g.crc_fin, g.syms
-    sess = lh.ReconSession([frames], device=local_rank, replicate=args.streams, share_records=False)
-    ctx = lh.CtxSession([frames], device=local_rank, replicate=args.streams)
+    cfg = CONFIGS[args.config]
+    per_gpu = args.streams or cfg["n"]
+    n_frames = args.frames or cfg["frames"]
+    # ---- the streams of this configuration, through the product's own host front end ------------------------------------------------------
+    distinct, datas, mains = [], [], []
+    for name in cfg["streams"]:
+        data = open(os.path.join(ROOT, "tests", "golden", "streams", name), "rb").read()
+        frames, perr, main_stream = lh.parse_file(data)
+        assert perr == "", perr
+        if n_frames:
+            frames = frames[:n_frames]
+        distinct.append(frames); datas.append(data); mains.append(main_stream)
+    # input bytes a stream stands for: the whole file, or the share of the pictures used
+    full = [lh.parse_file(d)[0] for d in datas] if n_frames else distinct
+    stream_bytes = [len(d) * sum(f.mb_w * f.mb_h for f in fr) / max(1, sum(f.mb_w * f.mb_h for f in fu)) for d, fr, fu in zip(datas, distinct, full)]
+    del full
+    # ---- the global stream list and this rank's share (static partition by macroblock count, no exchange during work) ----------
+    n_global = per_gpu * world
+    kind_of = [g % len(distinct) for g in range(n_global)]
+    work = [sum(f.mb_w * f.mb_h for f in distinct[k]) for k in kind_of]
+    g0, g1 = shard.partition_by_work(work, world)[rank]
+    my_kinds = kind_of[g0:g1]
+    # sessions take a list of distinct streams + a replica count: chain c holds distinct[c % len(distinct)]
+    assert all(my_kinds[i] == (my_kinds[0] + i) % len(distinct) for i in range(len(my_kinds)))
+    order = [distinct[(my_kinds[0] + i) % len(distinct)] for i in range(len(distinct))] if my_kinds else distinct
+    n_local = len(my_kinds)
+    assert n_local % len(distinct) == 0 or len(distinct) == 1
+    rep = max(1, n_local // len(distinct))
+    sess = lh.ReconSession(order, device=local_rank, replicate=rep, share_records=False)
+    ctx = lh.CtxSession(order, device=local_rank, replicate=rep)
+    out_cap = 1 << 16
+    while out_cap < 0.6 * max(stream_bytes):               # room for the largest tag of the largest stream
+        out_cap <<= 1
+    coder = lh.CoderSession(ctx, out_cap=out_cap)
+    local_bytes = sum(stream_bytes[k] for k in my_kinds)
 
-    def step():
-        sess.run()      # rows a1-a7: reconstruct + deblock + pad
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    k_ms = {"recon": 0.0, "ctx": 0.0, "coder": 0.0}
+
+    def step(timed=False):
+        if timed:
+            ev[0].record()
+        sess.run()      # rows a1-a7: reconstruct + deblock + pad (one launch of the dominant kernel)
+        if timed:
+            ev[1].record()
         ctx.run()       # row a8: per-coefficient context-model prior indices
+        if timed:
+            ev[2].record()
+        coder.run()     # rows a9/a10: binarisation, adaptive probabilities, bool coders -> the tagged byte streams
+        if timed:
+            ev[3].record()
 
     for _ in range(args.warmup):
         step()
@@ -153,117 +250,161 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # dominant kernel: launch duration from hipEvents on the launch stream (one launch == one step)
-    k_ms = sess.time_kernel(max(3, min(args.steps, 10)))
-    types = np.concatenate([f.mbs["mb_type"] for f in frames])
+    # per-stage device time, hipEvents on the launch stream (torch's current stream is the stream the C ABI launches on), a few extra steps
+    n_ev = max(2, min(args.steps, 5))
+    for _ in range(n_ev):
+        step(timed=True)
+        torch.cuda.synchronize(dev)
+        k_ms["recon"] += ev[0].elapsed_time(ev[1]); k_ms["ctx"] += ev[1].elapsed_time(ev[2]); k_ms["coder"] += ev[2].elapsed_time(ev[3])
+    for k in k_ms:
+        k_ms[k] /= n_ev
+    types = np.concatenate([f.mbs["mb_type"] for fr in order for f in fr])
     n_intra = int(np.count_nonzero(types & 0x207))
     n_inter = int(np.count_nonzero(types & 0x1F8))
-    alg_bytes = (n_intra * INTRA_BYTES_PER_MB + n_inter * INTER_BYTES_PER_MB) * args.streams
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    alg_bytes = (n_intra * INTRA_BYTES_PER_MB + n_inter * INTER_BYTES_PER_MB) * rep
+    achieved = alg_bytes / (k_ms["recon"] * 1e-3) / 1e9
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes from the
     # committed rocprofv3 --pmc passes over the same launch (profiles/traffic.json), corrected as the guide prescribes
     traffic = None
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["recon_chain_kernel"]
-        if t["streams"] == args.streams:
+        if t["streams"] == n_local and args.config == 1:
             traffic = (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
     except (OSError, KeyError, ValueError):
         pass
 
-    # parity spot check outside the timed region: last frame of two replicas against the reference's CRCs, and the
-    # context symbols of a frame against what the reference's model coded
-    for c in (0, args.streams - 1):
-        got = sess.picture(c, len(frames) - 1)
-        assert [golden_io.crc(g) for g in got] == frames[-1].crc_fin, "bench output differs from the reference"
-        ns, sy = ctx.frame_symbols(c, 7)
-        for k in range(len(ns)):
-            r = frames[7].syms[k]
-            assert ns[k] == len(r) and np.array_equal(sy[k][:ns[k]]["prior"], r["prior"]), "ctx symbols differ from the reference"
+    # the coder's own memory-bound figure: what its stages have to move (symbols read twice, 8-byte decision words and 2-byte list
+    # entries written once and read once, the bytes written)
+    dw, le = L.C.c_ulonglong(), L.C.c_ulonglong()
+    L.check(L.lib().lh264_code_last_totals(L.C.byref(dw), L.C.byref(le)))
+    n_ctx_syms = int(ctx.d_nsyms.view(torch.int16).to(torch.int64).sum().item())
+    n_syn_syms = sum(len(f.syn_syms) for fr in order for f in fr) * rep
+    lens = coder.d_len.cpu().numpy().reshape(n_local, L.N_TAG_SLOTS + 1)
+    assert not lens[:, L.N_TAG_SLOTS].any(), "device coder status %s" % sorted(set(lens[:, L.N_TAG_SLOTS].tolist()))
+    coded_local = lens[:, :35].astype(np.int64).sum(axis=1)
+    coder_bytes = 2 * 8 * (n_ctx_syms + n_syn_syms) + 2 * 8 * dw.value + 2 * 2 * le.value + int(coded_local.sum())
 
-    # rows a9/a10 (the adaptive arithmetic coder, on the device): timed as its own stage, not part of `value`
-    coder_info = None
-    if not args.no_coder:
-        coder = lh.CoderSession(ctx)
-        coder.run()
-        torch.cuda.synchronize(dev)
-        tc = time.perf_counter()
-        for _ in range(2):
-            coder.run()
-        torch.cuda.synchronize(dev)
-        c_ms = (time.perf_counter() - tc) / 2 * 1e3
-        coded = sum(len(v) for v in coder.tags(args.streams - 1).values())
-        # the reference writes 53,739 bytes for this stream, 997 of them the untagged main file: 52,742 tagged
-        assert coded == 52742, "coder output size differs from the reference (%d)" % coded
-        coder_info = {"ms": c_ms, "MB_per_s": args.streams * stream_bytes / c_ms / 1e3, "coded_bytes_per_stream": coded,
-                      "reference_tagged_bytes": 52742, "ratio_tagged": coded / stream_bytes,
-                      "note": "two waves per stream; throughput scales with the stream count (425 MB/s at 4096 streams)"}
-        # the whole compressed representation (default stream + tagged streams) against the reference's, and back again
-        tags = coder.tags(args.streams - 1)
-        assert len(main_stream) + coded == 53739, "compressed size differs from the reference's 53,739 bytes"
-        roundtrip = {"ratio": (len(main_stream) + coded) / stream_bytes, "reference_ratio": 53739 / 55885,
-                     "roundtrip_ok": lh.restore(main_stream, tags) == data}
+    # ---- parity outside the timed region ---------------------------------------------------------------------------------------------------
+    # every stream's compressed size must be what the reference wrote (fixture: the files of its console application), the last
+    # picture of the first and last replica must have the reference decoder's plane CRCs where the fixture has them
+    ref_tagged = []
+    for name in cfg["streams"]:
+        p = os.path.join(ROOT, "tests", "golden", "cli_" + name + ".npz")
+        if os.path.exists(p) and not n_frames:
+            z = np.load(p)
+            ref_tagged.append(sum(len(z[k]) for k in z.files if k.startswith("tag_")))
+        else:
+            ref_tagged.append(None)
+    for c in range(n_local):
+        want = ref_tagged[(my_kinds[0] + c) % len(distinct)]
+        assert want is None or int(coded_local[c]) == want, "stream %d: %d coded bytes, the reference wrote %d" % (c, coded_local[c], want)
+    roundtrip = None
+    if args.config == 1:
+        ref_frames = golden_io.load("bench_BA_MW_D.264")
+        for c in (0, n_local - 1):
+            got = sess.picture(c, len(order[0]) - 1)
+            assert [golden_io.crc(g) for g in got] == ref_frames[len(order[0]) - 1].crc_fin, "bench output differs from the reference"
+        tags = coder.tags(n_local - 1)
+        coded = sum(len(v) for v in tags.values())
+        assert len(mains[0]) + coded == 53739, "compressed size differs from the reference's 53,739 bytes"
+        roundtrip = {"ratio": (len(mains[0]) + coded) / len(datas[0]), "reference_ratio": 53739 / 55885, "roundtrip_ok": lh.restore(mains[0], tags) == datas[0]}
         assert roundtrip["roundtrip_ok"], "restore(compress(stream)) differs from the stream"
-        if rank == 0 and world == 1 and not args.no_cpu:
-            # host stages on this box's cores (rows f1 / f2): the front end (parse + default stream + syntax symbols) and the
-            # restore direction (adaptive decode + CAVLC writer), one stream per thread, bounded to a few seconds each
-            ncpu = min(16, len(os.sched_getaffinity(0)))      # a one-GPU box's CPU share is 16 cores
-            nb = 8 * ncpu
-            pt, npic = lh.parse_batch_time([data] * nb, ncpu, keep=False)     # pictures released as a pipeline would
-            assert npic == nb * len(frames)
-            pk, _ = lh.parse_batch_time([data] * nb, ncpu, keep=True)        # every picture of every stream held in memory
-            t0 = time.perf_counter()
-            outs = lh.restore_batch([(main_stream, tags)] * nb, ncpu)
-            rt = time.perf_counter() - t0
-            assert all(o == data for o in outs)
-            # the whole compress direction behind one C call, host bytes in -> host bytes out (parse, staging, PCIe, kernels, download)
-            lh.compress_batch([data] * 4, ncpu)
-            t0 = time.perf_counter()
-            e2e = lh.compress_batch([data] * (4 * nb), ncpu)
-            et = time.perf_counter() - t0
-            assert all(e is None for _, _, e in e2e) and e2e[-1][1] == tags and e2e[-1][0] == main_stream
-            del e2e
-            t0 = time.perf_counter()
-            e2e = lh.compress_batch([data] * (16 * nb), ncpu)          # four groups: parsing overlaps the device stage
-            et4 = time.perf_counter() - t0
-            assert all(e is None for _, _, e in e2e) and e2e[-1][1] == tags
-            del e2e
-            roundtrip["host_stages"] = {"threads": ncpu, "streams": nb, "front_end_MB_per_s": nb * stream_bytes / pt / 1e6,
-                                        "compress_batch_end_to_end_MB_per_s": 4 * nb * stream_bytes / et / 1e6, "compress_batch_streams": 4 * nb,
-                                        "compress_batch_end_to_end_%d_streams_MB_per_s" % (16 * nb): 16 * nb * stream_bytes / et4 / 1e6,
-                                        "front_end_keep_all_MB_per_s": nb * stream_bytes / pk / 1e6,
-                                        "restore_MB_per_s": nb * stream_bytes / rt / 1e6}
-        coder_info["roundtrip"] = roundtrip
-        # everything the compress direction does on the device, run back to back: a1-a8 (the timed step) + a9/a10 (this stage)
-        coder_info["device_compress_a1_a10_MB_per_s"] = args.streams * stream_bytes / (dt / args.steps * 1e3 + c_ms) / 1e3
-        del coder
+    else:
+        # ratio of what was coded: the tagged streams against the share of the input they stand for (the default stream is per file)
+        roundtrip = {"tagged_bytes_per_input_byte": float(coded_local.sum()) / max(1.0, local_bytes)}
+
+    # ---- multi-GPU: the per-stream result records of every rank, gathered and checked once on rank 0 ---------------------------------------
+    outv = coder.d_out.view(n_local, -1)
+    sums = torch.cat([outv[i:i + 8].sum(dim=1, dtype=torch.int64) for i in range(0, n_local, 8)]).cpu().numpy() if n_local else np.zeros(0, np.int64)
+    records = np.stack([np.arange(g0, g1, dtype=np.int64), coded_local, sums], axis=1) if n_local else np.zeros((0, 3), np.int64)
+    n_records = n_local
+    if dist is not None:
+        allrec = shard.gather_records(records, dist, device=dev)
+        n_records = len(allrec)
+        if rank == 0:
+            assert sorted(allrec[:, 0].tolist()) == list(range(n_global)), "a stream was compressed twice or not at all"
+            for k in range(len(distinct)):
+                rows = allrec[np.array([kind_of[int(g)] == k for g in allrec[:, 0]])]
+                assert len(set(map(tuple, rows[:, 1:].tolist()))) == 1, "replicas of one stream differ between ranks"
+
+    host_stages = None
+    if rank == 0 and world == 1 and not args.no_cpu and not args.no_host and args.config == 1:
+        # host stages on this box's cores (rows f1 / f2): the front end (parse + default stream + syntax symbols) and the restore
+        # direction (adaptive decode + CAVLC writer), one stream per thread, bounded to a few seconds each; and the whole compress
+        # direction behind one C call, host bytes in -> host bytes out (parse, staging, PCIe, kernels, download)
+        data = datas[0]
+        tags = coder.tags(n_local - 1)
+        ncpu = min(16, len(os.sched_getaffinity(0)))      # a one-GPU box's CPU share is 16 cores
+        nb = 8 * ncpu
+        pt, npic = lh.parse_batch_time([data] * nb, ncpu, keep=False)
+        assert npic == nb * len(order[0])
+        t1 = time.perf_counter()
+        outs = lh.restore_batch([(mains[0], tags)] * nb, ncpu)
+        rt = time.perf_counter() - t1
+        assert all(o == data for o in outs)
+        lh.compress_batch([data] * 4, ncpu)
+        t1 = time.perf_counter()
+        e2e = lh.compress_batch([data] * (4 * nb), ncpu)
+        et = time.perf_counter() - t1
+        assert all(e is None for _, _, e in e2e) and e2e[-1][1] == tags and e2e[-1][0] == mains[0]
+        del e2e
+        t1 = time.perf_counter()
+        e2e = lh.compress_batch([data] * (16 * nb), ncpu)          # four groups: parsing overlaps the device stage
+        et4 = time.perf_counter() - t1
+        assert all(e is None for _, _, e in e2e) and e2e[-1][1] == tags
+        del e2e
+        host_stages = {"threads": ncpu, "front_end_MB_per_s": nb * len(data) / pt / 1e6, "restore_MB_per_s": nb * len(data) / rt / 1e6,
+                       "compress_batch_end_to_end_%d_streams_MB_per_s" % (4 * nb): 4 * nb * len(data) / et / 1e6,
+                       "compress_batch_end_to_end_%d_streams_MB_per_s" % (16 * nb): 16 * nb * len(data) / et4 / 1e6}
 
     if rank == 0:
-        total_bytes = world * args.streams * stream_bytes * args.steps
+        ms = dt / args.steps * 1e3
+        total_bytes = local_bytes * world * args.steps        # every rank holds the same mix (weak scaling)
+        a18 = k_ms["recon"] + k_ms["ctx"]
+        what = cfg["what"] % ((per_gpu,) if args.config == 1 else (len(order[0]), per_gpu))
         out = {
             "metric": "MB/s .264 recompressed (bit-exact roundtrip) + ratio, 1/2/4/8 MI355X",
             "value": total_bytes / dt / 1e6, "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/int16", "data": "synthetic batch: res/BA_MW_D.264 parsed by the host front end, replicated",
-            "config": {"workload": "configs[1]: res/BA_MW_D.264 (QCIF, 100 frames) x %d independent streams per GPU" % args.streams,
-                       "streams_per_gpu": args.streams, "frames_per_stream": len(frames), "mbs_per_step_per_gpu": sess.n_mbs_total,
-                       "stages_in_timed_region": "a1-a7 (IDCT, intra/inter prediction, deblocking, reference padding) + a8 (context-model "
-                                                 "prior index per coefficient symbol); the host CAVLC parse is not in this step and the "
-                                                 "adaptive arithmetic coder (a9/a10, also on the device) is timed separately (coder_stage_a9_a10)",
-                       "parallelism": "one workgroup per stream, one wave per MB row; streams sharded across GPUs",
-                       "coder_stage_a9_a10": coder_info},
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int16", "data": "synthetic batch: reference-shipped / reference-encoded streams parsed by the host front end, replicated",
+            "config": {"workload": what, "streams_per_gpu": per_gpu, "frames_per_stream": [len(fr) for fr in order],
+                       "input_bytes_per_stream": stream_bytes, "mbs_per_step_per_gpu": sess.n_mbs_total,
+                       "stages_in_timed_region": "a1-a7 (IDCT, intra/inter prediction, deblocking, reference padding) + a8 (context-model prior index per "
+                                                 "coefficient symbol) + a9/a10 (binarisation, adaptive probabilities, bool coders): the whole compress direction "
+                                                 "on the device, records in HBM -> tagged byte streams in HBM; the host CAVLC/CABAC parse is not in this step",
+                       "parallelism": "reconstruct: one workgroup per stream, one wave per MB row; coder: one wave per macroblock (binarise), one workgroup per "
+                                      "stream (adaptive probabilities), one lane per (stream, tag) (bool coder); streams sharded across GPUs",
+                       "stage_ms": {"a1_a7_recon_chain_kernel": k_ms["recon"], "a8_ctx_kernels": k_ms["ctx"], "a9_a10_coder_kernels": k_ms["coder"]},
+                       "a1_a8_only_MB_per_s": local_bytes / (a18 * 1e-3) / 1e6,
+                       "compression": roundtrip, "host_stages": host_stages,
+                       "multi_gpu": {"result_records_gathered": n_records, "global_streams": n_global,
+                                     "measured_on_hardware": "this line" if world > 1 else "single GPU; N > 1 unmeasured in this run"}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "recon_chain_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": traffic, "kernel": "recon_chain_kernel", "kernel_ms": k_ms["recon"], "algorithmic_bytes_per_launch": alg_bytes,
+                         "coder_stage": {"bound": "hbm", "achieved": coder_bytes / (k_ms["coder"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": coder_bytes / (k_ms["coder"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": k_ms["coder"], "algorithmic_bytes": coder_bytes,
+                                         "note": "symbols read twice + 8-byte decision words and 2-byte list entries written and read once + output; "
+                                                 "the stage is bound by two serial chains (per adaptive probability, per tag), not by HBM"}},
         }
         if world == 1 and not args.no_cpu:
-            v, reps, secs = cpu_baseline(frames, stream_bytes, args.cpu_seconds)
-            out["cpu_baseline"] = {"value": v, "unit": "MB/s", "cores": 1, "kind": "port",
-                                   "sample": "oracle (C restatement of rows a1-a8) over BA_MW_D.264 x %d passes, %.1f s, 1 thread" % (reps, secs)}
-            ref = reference_cli_baseline(os.path.join(ROOT, "tests", "golden", "streams", "BA_MW_D.264"), stream_bytes)
+            ncpu = min(16, len(os.sched_getaffinity(0)))
+            v, reps, secs = cpu_baseline(order[0], stream_bytes[0], args.cpu_seconds, ncpu)
+            cpu_model = ""
+            try:
+                cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+            except (OSError, IndexError):
+                pass
+            out["cpu_baseline"] = {"value": v, "unit": "MB/s", "cores": ncpu, "kind": "port", "cpu": cpu_model,
+                                   "sample": "oracle (C restatement of rows a1-a8; the reference's coder a9/a10 is in reference_cli) over %s x %d passes on %d threads, "
+                                             "%.1f s" % (cfg["streams"][0], reps, ncpu, secs)}
+            nproc = max(1, min(ncpu, 4, int(os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / (12 << 30))))
+            ref = reference_cli_baseline(os.path.join(ROOT, "tests", "golden", "streams", cfg["streams"][0]), len(datas[0]), nproc)
             if ref is not None:
                 out["cpu_baseline"]["reference_cli"] = ref
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

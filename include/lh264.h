@@ -239,7 +239,9 @@ int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chai
  * compression_stream.h:353-487, bitwriter.h:35-105; DynProb :87-115; emitInt / emitUEGkInt :523-591).
  * The stream's symbols are binarised in parallel (one wave per macroblock); the adaptive probabilities are resolved by one
  * workgroup per stream, 64 decisions per wave step; one lane per (stream, tag) runs the bool coder.  The adaptive priors live in
- * a per-stream open-addressing hash table in HBM (a cell = 16 packed DynProbs = 64 bytes), zero-filled by the caller. */
+ * the LDS of the stream's workgroup; what does not fit is spilled to a per-stream open-addressing table in HBM (hash_cells_dev:
+ * hash_cap x 64 bytes = 8 x hash_cap entries of one DynProb each, zero-filled by the caller; a stream of N macroblocks touches
+ * roughly 2 N DynProbs, QCIF ... 1080p content measured). */
 #define LH264_N_TAG_SLOTS 40
 typedef struct lh264_code_job {
   const lh264_ctx_sym_t* syn_syms_dev;   /* host symbols of the picture, macroblock after macroblock        */
@@ -249,8 +251,8 @@ typedef struct lh264_code_job {
   int32_t n_mbs, reserved;
 } lh264_code_job_t;
 typedef struct lh264_code_stream {
-  uint32_t* hash_keys_dev;     /* hash_cap entries, zero-filled                                             */
-  uint32_t* hash_cells_dev;    /* hash_cap * 16, zero-filled                                                */
+  uint32_t* hash_keys_dev;     /* not used (ABI 1 kept the keys of the table here)                          */
+  uint32_t* hash_cells_dev;    /* hash_cap * 16 words, zero-filled: the spill table of the adaptive priors  */
   uint8_t*  out_dev;           /* LH264_N_TAG_SLOTS * out_cap bytes: slot t at t * out_cap                  */
   uint32_t* out_len_dev;       /* LH264_N_TAG_SLOTS lengths (0: tag never used); [LH264_N_TAG_SLOTS] = status (0 ok) */
   uint32_t  hash_cap;          /* power of two, at most 1 << 20                                             */
@@ -263,6 +265,10 @@ typedef struct lh264_code_stream {
  * when hip_stream has drained.  out_len_dev[LH264_N_TAG_SLOTS] != 0 reports 1: prior table full, 4: output overflow, 8: counter overflow. */
 int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
                        int n_chains, int n_jobs, long long total_mbs, int max_mbs_per_frame, void* hip_stream);
+/* sizes of the last lh264_code_chains call on the current device: 64-bit decision words written and read between its stages (one
+ * per binary decision, each stream's count rounded up to 64) and 16-bit tag-list entries (one per decision, each tag's list padded
+ * to 8): what the coder's memory traffic is computed from (bench.py). */
+int lh264_code_last_totals (unsigned long long* decision_words, unsigned long long* list_entries);
 
 /* ---- host front end: Annex-B bitstream -> macroblock records ------------------------------
  * Replaces, for the records the hot path needs, the reference's WelsDecodeBs / ParseNonVclNal / slice-header parse /

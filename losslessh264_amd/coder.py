@@ -10,7 +10,13 @@ TAG_OF_SLOT = list(range(34)) + [69]
 class CoderSession:
     """ctx: a CtxSession over the same streams (frames must carry syn_syms / syn_off from parse_stream)"""
 
-    def __init__(self, ctx, hash_cap=1 << 16, out_cap=1 << 16):
+    def __init__(self, ctx, hash_cap=None, out_cap=1 << 16):
+        if hash_cap is None:
+            # the spill table of a stream: 8 entries per "cell"; a stream touches about two adaptive probabilities per macroblock
+            mbs = max(sum(f.mb_w * f.mb_h for f in st) for st in ctx.streams)
+            hash_cap = 1 << 13
+            while hash_cap * 2 < mbs and hash_cap < (1 << 20):
+                hash_cap <<= 1
         assert hash_cap <= 1 << 20 and hash_cap & (hash_cap - 1) == 0
         torch = ctx.torch
         self.ctx, self.torch, self.lib, dev = ctx, torch, ctx.lib, ctx.dev
@@ -31,7 +37,7 @@ class CoderSession:
         self.d_off = torch.from_numpy(np.concatenate(offs)).to(dev)
         n_chains = ctx.n_chains
         self.hash_cap, self.out_cap = hash_cap, out_cap
-        self.d_keys = torch.zeros(n_chains * hash_cap, dtype=torch.int32, device=dev)
+        self.d_keys = torch.zeros(16, dtype=torch.int32, device=dev)          # unused by ABI 2
         self.d_cells = torch.zeros(n_chains * hash_cap * 16, dtype=torch.int32, device=dev)
         self.d_out = torch.zeros(n_chains * L.N_TAG_SLOTS * out_cap, dtype=torch.uint8, device=dev)
         self.d_len = torch.zeros(n_chains * (L.N_TAG_SLOTS + 1), dtype=torch.int32, device=dev)
@@ -50,7 +56,7 @@ class CoderSession:
                 j += 1
         st = np.zeros(n_chains, dtype=L.CODE_STREAM_DTYPE)
         for c in range(n_chains):
-            st[c]["hash_keys"] = self.d_keys.data_ptr() + c * hash_cap * 4
+            st[c]["hash_keys"] = self.d_keys.data_ptr()
             st[c]["hash_cells"] = self.d_cells.data_ptr() + c * hash_cap * 64
             st[c]["out"] = self.d_out.data_ptr() + c * L.N_TAG_SLOTS * out_cap
             st[c]["out_len"] = self.d_len.data_ptr() + c * (L.N_TAG_SLOTS + 1) * 4
@@ -62,7 +68,6 @@ class CoderSession:
 
     def run(self):
         """code every stream (the prior tables are adaptive state: cleared first)"""
-        self.d_keys.zero_()
         self.d_cells.zero_()
         L.check(self.lib.lh264_code_chains(self.d_jobs.data_ptr(), self.ctx.d_first.data_ptr(), self.d_streams.data_ptr(), self.n_chains,
                                            self.ctx.n_jobs, self.ctx.n_mbs_total, self.ctx.max_mbs,

@@ -182,6 +182,7 @@ struct CoderWs {
   void* small = nullptr; size_t small_cap = 0;     // job / macroblock / stream tables
   void* big = nullptr; size_t big_cap = 0;         // decision words + tag lists
   unsigned long long* totals_host = nullptr;       // page-locked, 2 x u64
+  unsigned long long last_words = 0, last_q = 0;   // of the last call: decisions (incl. per-stream padding to 64), list entries
 };
 CoderWs g_coder_ws[16];
 int grow (void** p, size_t* cap, size_t need) {
@@ -245,7 +246,18 @@ int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_fi
   const int groups = (n_chains + 63) / 64;
   hipLaunchKernelGGL (lh264::coder_code_kernel, dim3 ((unsigned)groups * 35), dim3 (64), 0, st, streams_dev, info, Q, n_chains, groups);
   HIPCHK (hipGetLastError());
+  W.last_words = n_words; W.last_q = n_q;
   // tag slots 35 .. LH264_N_TAG_SLOTS-1 do not exist: their lengths read 0
+  return LH264_OK;
+}
+
+int lh264_code_last_totals (unsigned long long* decision_words, unsigned long long* list_entries) {
+  int dev = 0;
+  if (lh264_device_count() <= 0 || hipGetDevice (&dev) != hipSuccess || dev < 0 || dev >= 16) return fail (LH264_E_NODEVICE, "no HIP device visible");
+  CoderWs& W = g_coder_ws[dev];
+  std::lock_guard<std::mutex> lock (W.mu);
+  if (decision_words) *decision_words = W.last_words;
+  if (list_entries) *list_entries = W.last_q;
   return LH264_OK;
 }
 

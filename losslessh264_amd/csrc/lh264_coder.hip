@@ -507,15 +507,17 @@ __device__ __forceinline__ uint32_t rs_hash (unsigned long long key) { return ((
 
 // the spill table: open addressing over the stream's `hash_cells_dev` memory (zero-filled by the caller), entries as above.  Only this
 // workgroup touches it; its accesses go to L2 (agent scope), never through this CU's L1.
-__device__ __forceinline__ void spill_put (GLB unsigned long long* T, uint32_t tmask, unsigned long long key, uint32_t st) {
+__device__ __forceinline__ bool spill_put (GLB unsigned long long* T, uint32_t tmask, unsigned long long key, uint32_t st) {
   const unsigned long long val = RS_ENT_MAKE (key, st);
   uint32_t h = rs_hash (key) >> 8;
   for (uint32_t tries = 0; tries <= tmask; tries++, h++) {
     GLB unsigned long long* p = T + (h & tmask);
     unsigned long long cur = __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == 0ull) { unsigned long long expect = 0ull; if (__hip_atomic_compare_exchange_strong (p, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; cur = expect; }
-    if (RS_ENT_KEY (cur) == key) { __hip_atomic_store (p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }      // (a key sits in one cache entry: nobody else writes it now)
+    if (cur == 0ull) { unsigned long long expect = 0ull; if (__hip_atomic_compare_exchange_strong (p, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true; cur = expect; }
+    if (RS_ENT_KEY (cur) == key) { __hip_atomic_store (p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }      // (a key sits in one cache entry: nobody else writes it now)
+    if (tries >= 4096u) break;
   }
+  return false;                  // the table is (as good as) full
 }
 __device__ __forceinline__ uint32_t spill_get (const GLB unsigned long long* T, uint32_t tmask, unsigned long long key, unsigned long long first) {
   uint32_t h = rs_hash (key) >> 8;
@@ -740,7 +742,11 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
         rs_barrier();
         for (int i = tid; i < RS_SLOTS; i += RS_WAVES * 64) {
           const unsigned long long e = S.ent[i];
-          if (e) { spill_put (T, tmask, RS_ENT_KEY (e), (uint32_t)e & 0xfffffu); S.ent[i] = 0ull; }
+          if (e) {
+            if (!spill_put (T, tmask, RS_ENT_KEY (e), (uint32_t)e & 0xfffffu))
+              atomicOr (&chain_info[(size_t)chain * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_TABLE_FULL);
+            S.ent[i] = 0ull;
+          }
         }
         if (tid == 0) S.nres = 0;
         asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");

@@ -127,8 +127,8 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   std::vector<size_t> key0 (n_chains + 1, 0), out0 (n_chains + 1, 0);
   for (int c = 0; c < n_chains; c++) {
     const size_t mbs = mb0[c + 1] - mb0[c];
-    uint32_t hc = 1u << 16;
-    while (hc < mbs * 8 && hc < (1u << 20)) hc <<= 1;       // cells touched grow far slower than macroblocks; status 1 reports a full table
+    uint32_t hc = 1u << 13;                                   // 8 spill entries per cell; about two adaptive probabilities per macroblock
+    while (hc * 2 < mbs && hc < (1u << 20)) hc <<= 1;        // status 1 reports a full table
     hash_cap[c] = hc; key0[c + 1] = key0[c] + hc;
     out_cap[c] = (uint32_t)std::max<size_t> (1u << 16, 2 * len[idx[c]] + 4096);
     out0[c + 1] = out0[c] + (size_t)LH264_N_TAG_SLOTS * out_cap[c];
@@ -139,7 +139,7 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
                   A.d_nnz.alloc (n_mbs * 24, true) && A.d_syms.alloc (n_mbs * LH264_CTX_MAX_SYMS * sizeof (lh264_ctx_sym_t), false) && A.d_nsyms.alloc (n_mbs * 2, true) &&
                   A.d_cj.alloc (n_jobs * sizeof (lh264_ctx_job_t), false) && A.d_first.alloc ((n_chains + 1) * 4, false) && A.d_syn.alloc (n_syn * sizeof (lh264_ctx_sym_t), false) &&
                   A.d_off.alloc (n_off * 4, false) && A.d_kj.alloc (n_jobs * sizeof (lh264_code_job_t), false) && A.d_st.alloc (n_chains * sizeof (lh264_code_stream_t), false) &&
-                  A.d_keys.alloc (keys_total * 4, true) && A.d_cells.alloc (keys_total * 64, true) && A.d_out.alloc (out_total, false) &&
+                  A.d_keys.alloc (256, false) && A.d_cells.alloc (keys_total * 64, true) && A.d_out.alloc (out_total, false) &&
                   A.d_len.alloc ((size_t)n_chains * (LH264_N_TAG_SLOTS + 1) * 4, true) &&
                   A.h_mbs.alloc (n_mbs * sizeof (lh264_mb_t)) && A.h_sparse.alloc (n_sparse * 8) && A.h_sl.alloc (n_slices * sizeof (lh264_slice_t)) &&
                   A.h_syn.alloc (n_syn * sizeof (lh264_ctx_sym_t)) && A.h_off.alloc (n_off * 4);
@@ -176,7 +176,7 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
       mo += n; so += f.slices.size(); yo += f.syn_syms.size(); oo += n + 1; j++;
     }
     lh264_code_stream_t& st = h_st[c];
-    st.hash_keys_dev = A.d_keys.as<uint32_t>() + key0[c]; st.hash_cells_dev = A.d_cells.as<uint32_t>() + key0[c] * 16;
+    st.hash_keys_dev = A.d_keys.as<uint32_t>(); st.hash_cells_dev = A.d_cells.as<uint32_t>() + key0[c] * 16;
     st.out_dev = A.d_out.as<uint8_t>() + out0[c]; st.out_len_dev = A.d_len.as<uint32_t>() + (size_t)c * (LH264_N_TAG_SLOTS + 1);
     st.hash_cap = hash_cap[c]; st.out_cap = out_cap[c];
   });

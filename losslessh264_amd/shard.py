@@ -21,18 +21,20 @@ def partition_by_work(work, world_size):
     return bounds
 
 
-def gather_records(local_records, dist):
-    """fixed-size int64 result records (e.g. stream id, bytes, checksum) of every rank -> one array on all ranks"""
+def gather_records(local_records, dist, device=None):
+    """fixed-size int64 result records (e.g. stream id, bytes, checksum) of every rank -> one array on all ranks.
+    device: where the collective's tensors live (the rank's GPU under RCCL; None = host memory, gloo)"""
     import torch
     rec = torch.as_tensor(np.asarray(local_records, dtype=np.int64))
     if rec.ndim == 1:
         rec = rec.reshape(-1, 1)
-    n_local = torch.tensor([rec.shape[0]], dtype=torch.int64)
-    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(dist.get_world_size())]
+    rec = rec.to(device) if device is not None else rec
+    n_local = torch.tensor([rec.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(dist.get_world_size())]
     dist.all_gather(counts, n_local)
     nmax = int(max(int(c.item()) for c in counts))
-    pad = torch.zeros((nmax, rec.shape[1]), dtype=torch.int64)
+    pad = torch.zeros((nmax, rec.shape[1]), dtype=torch.int64, device=device)
     pad[:rec.shape[0]] = rec
     out = [torch.zeros_like(pad) for _ in range(dist.get_world_size())]
     dist.all_gather(out, pad)
-    return np.concatenate([o[:int(c.item())].numpy() for o, c in zip(out, counts)], axis=0)
+    return np.concatenate([o[:int(c.item())].cpu().numpy() for o, c in zip(out, counts)], axis=0)

@@ -45,7 +45,13 @@ def main():
     encode(tmp, "a.yuv", 1280, 720, 2, os.path.join(dst, "syn720p_allI_4slices.264"), 1, ["-slcmd", "0", "1", "-slcnum", "0", "4"])
     pattern(os.path.join(tmp, "b.yuv"), 1920, 1080, 2, True)
     encode(tmp, "b.yuv", 1920, 1080, 2, os.path.join(dst, "syn1080p_IP.264"), 16, ["-slcmd", "0", "0"])
-    for n in ("syn720p_allI_4slices.264", "syn1080p_IP.264"):
+    # the bench workloads of configs[2] / configs[3]: the same patterns, 8 pictures (the first two pictures are NOT the files above:
+    # the encoder's rate-free QP 26 path is deterministic, the noise of the all-intra pattern is drawn per picture from one generator)
+    pattern(os.path.join(tmp, "c.yuv"), 1280, 720, 8, False)
+    encode(tmp, "c.yuv", 1280, 720, 8, os.path.join(dst, "syn720p_allI_4slices_8f.264"), 1, ["-slcmd", "0", "1", "-slcnum", "0", "4"])
+    pattern(os.path.join(tmp, "d.yuv"), 1920, 1080, 8, True)
+    encode(tmp, "d.yuv", 1920, 1080, 8, os.path.join(dst, "syn1080p_IP_8f.264"), 16, ["-slcmd", "0", "0"])
+    for n in ("syn720p_allI_4slices.264", "syn1080p_IP.264", "syn720p_allI_4slices_8f.264", "syn1080p_IP_8f.264"):
         print(n, os.path.getsize(os.path.join(dst, n)), "bytes")
     shutil.rmtree(tmp)
 

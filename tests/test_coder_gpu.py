@@ -70,7 +70,7 @@ def test_whole_stream_compress_equals_reference_cli_and_round_trips():
         datas.append(data); streams.append(frames); mains.append(main)
     ctx = lh.CtxSession(streams)
     ctx.run()
-    coder = lh.CoderSession(ctx, hash_cap=1 << 18, out_cap=1 << 19)
+    coder = lh.CoderSession(ctx, hash_cap=1 << 18, out_cap=1 << 20)
     coder.run()
     ctx.synchronize()
     for c, name in enumerate(CLI):

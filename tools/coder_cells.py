@@ -12,7 +12,7 @@ for name in sys.argv[1:] or ["BA_MW_D.264"]:
     ctx = lh.CtxSession([frames], replicate=2)
     coder = lh.CoderSession(ctx, hash_cap=1 << 18, out_cap=1 << 20)
     ctx.run(); coder.run(); ctx.synchronize()
-    keys = coder.d_keys[:coder.hash_cap].cpu().numpy()
+    keys = np.zeros(1)
     cells = coder.d_cells[:coder.hash_cap * 16].cpu().numpy().reshape(-1, 16)
     used = keys != 0
     print(name, "frames", len(frames), "mbs", sum(f.mb_w * f.mb_h for f in frames), "distinct cells", int(used.sum()),

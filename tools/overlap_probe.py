@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""the whole device compress (rows a1-a10) run back to back on one HIP stream, and with the reconstruct kernel on a second stream
+beside the context-index + coder stages (they read different buffers): ms per step for N replicas of the bench stream"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import losslessh264_amd as lh
+streams = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+data = open(os.path.join(ROOT, "tests", "golden", "streams", "BA_MW_D.264"), "rb").read()
+frames, err, main = lh.parse_file(data)
+sess = lh.ReconSession([frames], replicate=streams, share_records=False)
+ctx = lh.CtxSession([frames], replicate=streams)
+coder = lh.CoderSession(ctx)
+dev = sess.dev
+s2 = torch.cuda.Stream(dev)
+def serial():
+    sess.run(); ctx.run(); coder.run()
+def overlapped():
+    s2.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(s2):
+        sess.run()
+    ctx.run(); coder.run()
+    torch.cuda.current_stream(dev).wait_stream(s2)
+for name, fn in (("one stream", serial), ("two streams", overlapped), ("one stream", serial), ("two streams", overlapped)):
+    fn(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / 5
+    print("%-12s %.2f ms per step = %.0f MB/s of .264 (a1-a10), coded %d" % (name, dt * 1e3, streams * len(data) / dt / 1e6, sum(len(v) for v in coder.tags(streams - 1).values())), flush=True)
