@@ -1000,6 +1000,14 @@ __device__ LH264_PHASE void deblock_phase (LDS WaveLds& L, const LDS WgLds& G, R
   const int bec = tab[TAB_BETA + tab_idx (qc + bo)], bel = tab[TAB_BETA + tab_idx (ql + bo)], bet = tab[TAB_BETA + tab_idx (qt + bo)];
   const uint32_t tcc = * (const LDS uint32_t*)&tab[TAB_TC0 + 4 * iac], tcl = * (const LDS uint32_t*)&tab[TAB_TC0 + 4 * ial],
                  tct = * (const LDS uint32_t*)&tab[TAB_TC0 + 4 * iat];
+  // Reference behaviour kept bit for bit: for an INTRA macroblock whose Cb and Cr QPs differ, FilteringEdgeChromaHV looks tc0 up
+  // in its "chroma v" loop only; its "chroma h" loop (deblocking.cpp:786-807) filters the inner edge of each plane with what that
+  // loop left behind - Cr's tc0 whenever Cr's alpha | beta is nonzero.  So Cb's inner horizontal edge takes Cr's tc0 then.
+  uint32_t tcc_h = tcc;
+  if (mintra && uni (m.qp_c (0)) != uni (m.qp_c (1))) {
+    const int qr = m.qp_c (1), iar = tab_idx (qr + ao);
+    if (chroma && cpl == 0 && (tab[TAB_ALPHA + iar] | tab[TAB_BETA + tab_idx (qr + bo)])) tcc_h = * (const LDS uint32_t*)&tab[TAB_TC0 + 4 * iar];
+  }
   int v[20];
   if (any0) {
     // ---- vertical edges: line = row li, samples -4..15 (chroma -4..7) ------------------------------------------
@@ -1042,7 +1050,7 @@ __device__ LH264_PHASE void deblock_phase (LDS WaveLds& L, const LDS WgLds& G, R
       const uint32_t bc = k == 0 ? bs1.x : k == 1 ? bs1.z : 0u;
       const int bs = (int) (((chroma ? bc : bl) >> sh8) & 0xff);
       const int alpha = k == 0 ? alt : alc, beta = k == 0 ? bet : bec;
-      const uint32_t tcw = k == 0 ? tct : tcc;
+      const uint32_t tcw = k == 0 ? tct : tcc_h;
       filter_edge (v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], v[4 * k + 4], v[4 * k + 5], v[4 * k + 6], v[4 * k + 7],
                    (alpha | beta) ? bs : 0, alpha, beta, (int) ((tcw >> (8 * (bs & 3))) & 0xff), chroma);
     }

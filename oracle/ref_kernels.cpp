@@ -14,6 +14,9 @@
 #include "deblocking_common.h"
 #include "expand_pic.h"
 #include "mc.h"
+#include "deblocking.h"
+#include "../include/lh264.h"   /* our record layout (input of the shim) */
+#include <vector>
 
 using namespace WelsDec;
 
@@ -96,6 +99,45 @@ void refk_expand_picture (uint8_t* y, uint8_t* u, uint8_t* v, int w, int h, int 
   uint8_t* data[3] = {y, u, v};
   int32_t st[3] = {stride_y, stride_c, stride_c};
   ExpandReferencingPicture (data, w, h, st, f.pfExpandLumaPicture, f.pfExpandChromaPicture);
+}
+
+// The reference's per-macroblock deblocking drivers (WelsDeblockingMb -> DeblockingIntraMb / DeblockingInterMb with the boundary
+// strength derivation, deblocking.cpp:160-352,568-862) over a whole synthetic picture in raster order, the way
+// WelsDeblockingFilterSlice (:872-934) walks a slice: the layer's per-macroblock arrays are filled from our records, the planes are
+// filtered in place.  Pattern of the reference's own test/decoder/DecUT_DeblockCommon.cpp:417-979.
+void refk_deblock_picture (const lh264_mb_t* mbs, const lh264_slice_t* slices, int mb_w, int mb_h, uint8_t* y, uint8_t* u, uint8_t* v,
+                           int stride_y, int stride_c) {
+  const int n = mb_w * mb_h;
+  SDqLayer L; memset (&L, 0, sizeof (L));
+  std::vector<int16_t> type (n); std::vector<int32_t> sidc (n); std::vector<int8_t> qp (n);
+  std::vector<int8_t> cqp (2 * n), nzc (24 * n), ref (16 * n); std::vector<int16_t> mv (32 * n);
+  bool* t8 = (bool*)calloc (n, sizeof (bool));
+  for (int k = 0; k < n; k++) {
+    const lh264_mb_t& m = mbs[k];
+    type[k] = (int16_t)m.mb_type; sidc[k] = m.slice_id; qp[k] = (int8_t)m.qp_y; cqp[2 * k] = (int8_t)m.qp_c[0]; cqp[2 * k + 1] = (int8_t)m.qp_c[1];
+    t8[k] = (m.flags & LH264_MBF_T8x8) != 0;
+    for (int i = 0; i < 24; i++) nzc[24 * k + i] = m.nzc[i] != 0;      // as the reconstruction leaves them (pWelsSetNonZeroCountFunc, decode_slice.cpp:266-267)
+    for (int b = 0; b < 16; b++) {
+      mv[32 * k + 2 * b] = m.mv[b][0]; mv[32 * k + 2 * b + 1] = m.mv[b][1];
+      ref[16 * k + b] = m.ref_idx[((b >> 3) << 1) + ((b & 3) >> 1)];
+    }
+  }
+  L.pMbType = type.data(); L.pSliceIdc = sidc.data(); L.pLumaQp = qp.data();
+  L.pChromaQp = (int8_t (*)[2])cqp.data(); L.pNzc = (int8_t (*)[24])nzc.data();
+  L.pMv[0] = (int16_t (*)[16][2])mv.data(); L.pRefIndex[0] = (int8_t (*)[16])ref.data();
+  L.pTransformSize8x8Flag = t8; L.iMbWidth = mb_w; L.iMbHeight = mb_h;
+  SDeblockingFunc fn; DeblockingInit (&fn, 0);
+  SDeblockingFilter F; memset (&F, 0, sizeof (F));
+  F.pCsData[0] = y; F.pCsData[1] = u; F.pCsData[2] = v; F.iCsStride[0] = stride_y; F.iCsStride[1] = stride_c;
+  F.pLoopf = &fn;
+  for (int k = 0; k < n; k++) {
+    const lh264_slice_t& sl = slices[mbs[k].slice_id];          // the slice header fields WelsDeblockingFilterSlice copies (:893-899)
+    if (sl.deblock_idc == 1) continue;
+    F.iSliceAlphaC0Offset = sl.alpha_c0_offset; F.iSliceBetaOffset = sl.beta_offset;
+    L.iMbX = k % mb_w; L.iMbY = k / mb_w; L.iMbXyIndex = k;
+    WelsDeblockingMb (&L, &F, DeblockingAvailableNoInterlayer (&L, sl.deblock_idc));
+  }
+  free (t8);
 }
 
 }  // extern "C"

@@ -155,6 +155,41 @@ def test_deblock_edge_filters(libs):
             assert np.array_equal(a, b), (name, vert)
 
 
+def test_deblock_macroblock_drivers(libs):
+    """WelsDeblockingMb / DeblockingIntraMb / DeblockingInterMb with the boundary-strength derivation (deblocking.cpp:160-352,
+    568-862) over whole synthetic pictures (the pattern of test/decoder/DecUT_DeblockCommon.cpp:417-979): random macroblock types,
+    QPs with Cb != Cr, coefficients, vectors, reference indices, 8x8 transform, non-zero alpha / beta offsets, several slices with
+    disable_deblocking_filter_idc 0 / 1 / 2.  Includes the reference's stale-iTc inner chroma edge of intra macroblocks (:786-807)."""
+    import synth
+    orc, ref = libs
+    cases = [dict(seed=11, p_frames=False), dict(seed=12, p_frames=True), dict(seed=13, p_frames=True, t8=True),
+             dict(seed=14, p_frames=True, n_slices=3, idc=3), dict(seed=15, p_frames=False, t8=True, n_slices=2, idc=2),
+             dict(seed=16, p_frames=True, pcm=True)]
+    n_stale = 0
+    for kw in cases:
+        seed = kw.pop("seed")
+        for f in synth.make_stream(seed, 7, 5, 3, **kw):
+            rng = np.random.default_rng(1000 + seed + f.id)
+            a = O.HostPic(f.mb_w, f.mb_h, fill=0)
+            base = rng.integers(40, 216)
+            for p in range(3):      # smooth content with small steps at block edges: every branch of the filters is reached
+                pl = a.plane(p)
+                pl[:] = np.clip(base + rng.integers(-9, 10, pl.shape) + 6 * ((np.arange(pl.shape[1]) // 4) % 3)[None, :], 0, 255)
+            b = O.HostPic(f.mb_w, f.mb_h, fill=0)
+            b.buf[:] = a.buf
+            mbs = np.ascontiguousarray(f.mbs); sl = np.ascontiguousarray(f.slices)
+            sa = a.struct()
+            for si in range(len(sl)):
+                orc.orc_deblock_slice(_p(mbs), _p(sl), si, C.byref(sa), f.mb_w, f.mb_h)
+            sb = b.struct()
+            ref.refk_deblock_picture(_p(mbs), _p(sl), f.mb_w, f.mb_h, C.c_void_p(sb.y), C.c_void_p(sb.u), C.c_void_p(sb.v), sb.stride_y, sb.stride_c)
+            for p in range(3):
+                assert np.array_equal(a.plane(p), b.plane(p)), (seed, f.id, p)
+            intra = (mbs["mb_type"] & 0x207) != 0
+            n_stale += int(np.count_nonzero(intra & (mbs["qp_c"][:, 0] != mbs["qp_c"][:, 1])))
+    assert n_stale > 50         # the quirk's precondition is exercised
+
+
 def test_expand(libs):
     orc, ref = libs
     rng = np.random.default_rng(8)
