@@ -12,10 +12,11 @@ class CoderSession:
 
     def __init__(self, ctx, hash_cap=None, out_cap=1 << 16):
         if hash_cap is None:
-            # the spill table of a stream: 8 entries per "cell"; a stream touches about two adaptive probabilities per macroblock
-            mbs = max(sum(f.mb_w * f.mb_h for f in st) for st in ctx.streams)
+            # the spill table of a stream (8 entries per "cell"): room for four adaptive probabilities per coded coefficient - measured:
+            # 0.1 .. 0.5 per coefficient, the more the higher the bit rate
+            nz = max(sum(int(np.count_nonzero(f.levels)) for f in st) for st in ctx.streams)
             hash_cap = 1 << 13
-            while hash_cap * 2 < mbs and hash_cap < (1 << 20):
+            while hash_cap * 2 < nz and hash_cap < (1 << 20):
                 hash_cap <<= 1
         assert hash_cap <= 1 << 20 and hash_cap & (hash_cap - 1) == 0
         torch = ctx.torch

@@ -127,8 +127,8 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   std::vector<size_t> key0 (n_chains + 1, 0), out0 (n_chains + 1, 0);
   for (int c = 0; c < n_chains; c++) {
     const size_t mbs = mb0[c + 1] - mb0[c];
-    uint32_t hc = 1u << 13;                                   // 8 spill entries per cell; about two adaptive probabilities per macroblock
-    while (hc * 2 < mbs && hc < (1u << 20)) hc <<= 1;        // status 1 reports a full table
+    uint32_t hc = 1u << 13;                                   // 8 spill entries per cell: four entries per input byte (a stream touches
+    while ((size_t)hc * 2 < len[idx[c]] && hc < (1u << 20)) hc <<= 1;      // 0.2 .. 0.5 adaptive probabilities per byte); status 1 reports a full table
     hash_cap[c] = hc; key0[c + 1] = key0[c] + hc;
     out_cap[c] = (uint32_t)std::max<size_t> (1u << 16, 2 * len[idx[c]] + 4096);
     out0[c + 1] = out0[c] + (size_t)LH264_N_TAG_SLOTS * out_cap[c];
