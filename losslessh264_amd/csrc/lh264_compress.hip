@@ -245,9 +245,10 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
   // Streams are parsed in waves on the host threads; parsed streams collect into a group until the group is worth a launch
   // (bounded by macroblock count: the symbol buffer takes 3.4 KB per macroblock); the group's staging, upload, kernels and
   // download run on their own host thread while the next wave is being parsed.
-  // one launch of the coder takes ~0.12 s however few streams it codes, and a group of this size takes about as long to parse
-  // as its device stage lasts: smaller groups only add launches
-  const size_t kBudget = 5200000;
+  // the device stage of a group is bound by the per-stream serial chains of the coder (about 15 ms for 100 QCIF pictures, whatever the
+  // number of streams above a few hundred), its parse by the host threads (0.2 us per macroblock and thread): groups of this size keep
+  // both sides busy, so that a batch of a few hundred streams already overlaps parsing with the device stage
+  const size_t kBudget = 1300000;
   const int kWave = std::max (8, 4 * threads);
   // device and page-locked buffers live across calls (allocating and releasing ~20 GB costs more than a whole batch):
   // one arena per process, one compress call at a time; lh264_compress_release() gives the memory back
