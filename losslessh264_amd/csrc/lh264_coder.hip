@@ -730,8 +730,9 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
       // ---- afterwards: the probability, and the entry of the tag's list ------------------------------------------------------------------
       // (stored at the top of the next step: a store as the youngest memory operation at the loop's end would make the compiler's
       // wait for the spill-table answers wait for the store as well)
+      // the list entry carries the probability of the bit that occurred (what the bool coder multiplies with, see bc_step)
       const uint32_t prob = dp_ratio (a0, a1);
-      pend_ok = v_cur; pend_q = cb + (uint32_t)trank; pend_v = prob << 1 | (uint32_t)bit;
+      pend_ok = v_cur; pend_q = cb + (uint32_t)trank; pend_v = (bit ? 256u - prob : prob) << 1 | (uint32_t)bit;
     }
     RS_STAMP (3)
     {
@@ -772,7 +773,8 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
 
 // ---- kernel 6: per (stream, tag) the libvpx bool coder (vpx_writer, bitwriter.h:35-105) with the carry resolved in registers -----
 struct Bc {
-  uint32_t low, range, pos, ffrun;
+  unsigned long long low64;
+  uint32_t range, pos, ffrun;
   int count, pending, last;
 };
 __device__ __forceinline__ void bc_put (Bc& b, GLB uint8_t* out, uint32_t cap, int byte) {
@@ -793,27 +795,36 @@ __device__ __forceinline__ void bc_byte (Bc& b, GLB uint8_t* out, uint32_t cap, 
     b.ffrun = 0; b.pending = byte;
   }
 }
-__device__ __forceinline__ void bc_write (Bc& b, GLB uint8_t* out, uint32_t cap, int bit, int prob) {      // vpx_write
-  const uint32_t split = 1u + (__umul24 (b.range - 1u, (uint32_t)prob) >> 8);          // both factors < 256
-  uint32_t range = split, low = b.low;
-  if (bit) { low += split; range = b.range - split; }
-  int shift = range < 128u ? __clz ((int)range) - 24 : 0;          // vpx_norm[range]
-  range <<= shift;
-  int count = b.count + shift;
-  if (count >= 0) {
-    const int offset = shift - count;
-    const bool carry = ((low << (offset - 1)) & 0x80000000u) != 0;
-    bc_byte (b, out, cap, (int) ((low >> (24 - offset)) & 0xffu), carry);
-    low <<= offset;
-    shift = count;
-    low &= 0xffffffu;
-    count -= 8;
+// vpx_write (bitwriter.h:35-105), cut in two so that the per-decision part is short (a single in-order wave pays every instruction):
+// bc_step adds and shifts in a 64-bit `low` and only counts the bits; bc_drain, called every few decisions, takes the bytes that
+// have become complete out of `low` (vpx_write does so at once, one byte at a time: the bytes are those of the same big number, and
+// a carry a later decision produces goes into the held bytes exactly as vpx_write's backward carry loop does).
+// Between drains at most four decisions: count < 28, low < 2^(24 + 28 + 9).
+// A list entry is e = q << 1 | bit with q = the probability of the bit that occurred, in 1/256 (bit 0: the decision's probability p,
+// bit 1: 256 - p; written so by the resolve kernel).  With x = range - 1:  bit 0: what is left is split = (x p + 256) >> 8;  bit 1:
+// range - split = x - (x p >> 8) = (x (256 - p) + 255) >> 8.  One multiply-add for both, nothing on the serial chain but
+// mad -> shift -> count-leading-zeros -> shift.
+__device__ __forceinline__ void bc_step (Bc& b, uint32_t e) {
+  const uint32_t bit = e & 1u, q = e >> 1;
+  const uint32_t r = (__umul24 (b.range, q) + (256u - bit - q)) >> 8;                          // ((range - 1) q + 256 - bit) >> 8
+  b.low64 += (unsigned long long) ((b.range - r) & (0u - bit));                               // bit 1: low += split
+  const int shift = __clz ((int)r) - 24;                                                       // vpx_norm[r]: 1 <= r <= 255
+  b.range = r << shift;
+  b.low64 <<= shift;
+  b.count += shift;
+}
+__device__ __forceinline__ void bc_drain (Bc& b, GLB uint8_t* out, uint32_t cap) {
+  while (b.count >= 0) {
+    // 24 + count bits lie below the byte that is complete; the bit above it is a carry into what was put out before
+    const int below = 24 + b.count;
+    const uint32_t top = (uint32_t) (b.low64 >> below);
+    bc_byte (b, out, cap, (int) (top & 0xffu), (top & 0x100u) != 0);
+    b.low64 &= (1ull << below) - 1ull;
+    b.count -= 8;
   }
-  low <<= shift;
-  b.count = count; b.low = low; b.range = range;
 }
 __device__ __forceinline__ void bc_finish (Bc& b, GLB uint8_t* out, uint32_t cap) {      // vpx_stop_encode + flush of the held bytes
-  for (int i = 0; i < 32; i++) bc_write (b, out, cap, 0, 128);
+  for (int i = 0; i < 32; i++) { bc_step (b, 128u << 1); bc_drain (b, out, cap); }
   if (b.pending >= 0) {
     bc_put (b, out, cap, b.pending);
     for (uint32_t i = 0; i < b.ffrun; i++) bc_put (b, out, cap, 0xff);
@@ -837,7 +848,7 @@ coder_code_kernel (const lh264_code_stream_t* __restrict__ streams, const uint32
   const uint32_t cap = S->out_cap;
   GLB uint8_t* o = glb<uint8_t> (S->out_dev) + (size_t)slot * cap;
   Bc bc;
-  bc.pos = 0; bc.low = 0; bc.range = 255; bc.count = -24; bc.ffrun = 0; bc.pending = -1; bc.last = 0;
+  bc.pos = 0; bc.low64 = 0; bc.range = 255; bc.count = -24; bc.ffrun = 0; bc.pending = -1; bc.last = 0;
   // the list is read four 16-byte pieces ahead of the coder (each piece is a memory round trip of its own for every lane)
   const uint32_t pieces = (n + 7u) >> 3;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -847,19 +858,16 @@ coder_code_kernel (const lh264_code_stream_t* __restrict__ streams, const uint32
     p0 = p1; p1 = p2; p2 = p3; p3 = c + 4 < pieces ? src[c + 4] : zero4;
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
     const uint32_t q = c << 3;
-    if (q + 8u <= n) {                    // a whole piece: no per-decision test
+    if (q + 8u <= n) {                    // a whole piece: no per-decision test, the bytes taken out twice
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        const uint32_t e = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-        bc_write (bc, o, cap, (int) (e & 1u), (int) (e >> 1));
+        bc_step (bc, (w[i >> 1] >> (16 * (i & 1))) & 0x3ffu);
+        if ((i & 3) == 3) bc_drain (bc, o, cap);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        if (q + (uint32_t)i < n) {
-          const uint32_t e = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-          bc_write (bc, o, cap, (int) (e & 1u), (int) (e >> 1));
-        }
+        if (q + (uint32_t)i < n) { bc_step (bc, (w[i >> 1] >> (16 * (i & 1))) & 0x3ffu); bc_drain (bc, o, cap); }
       }
     }
   }

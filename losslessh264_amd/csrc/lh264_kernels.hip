@@ -1072,13 +1072,27 @@ struct RowBufs {
   int LY, LC, FW;                               // layout of a slot
 };
 
+// Wait until the wave of the row above has finished `need` (encoded as in WgLds::progress); nothing to wait for in the first row.
+__device__ __forceinline__ void wait_row_above (volatile LDS int* prog_above, int need, bool have_row_above) {
+  if (have_row_above) {
+    while ((int) (*prog_above - need) < 0) __builtin_amdgcn_s_sleep (1);
+    wsync();
+  }
+}
+
 __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, const LDS WgLds& G, const RowBufs& B, const Pref& pf,
-                                            int mbx, int mby, int par, int& slc_id, bool pub_line, bool pub_left, int lane
+                                            int mbx, int mby, int par, int& slc_id, bool pub_line, bool pub_left, int lane,
+                                            volatile LDS int* prog_above, int need_above
 #ifdef LH264_STAMP
                                             , unsigned long long& st_t0, unsigned long long* st_acc
 #endif
                                            ) {
   LDS uint8_t* T = L.T;
+  // The row above must be two macroblocks ahead (top-right neighbour of intra prediction; raster order of the in-loop filter).  Only
+  // an INTRA macroblock needs that before it starts: inter prediction and the residual read nothing of the row above, so every other
+  // macroblock predicts first and waits where its filter takes the neighbours' filtered samples - the wait overlaps its own work.
+  const bool early_wait = (uni ((int)pf.rec) & LH264_MB_INTRA) != 0;         // lane 0 holds the record's first dword: mb_type in the low half
+  if (early_wait) wait_row_above (prog_above, need_above, mby > 0);
   // ---- 0. stage the prefetched records ----------------------------------------------------------
   if (lane < 32) L.rec[par][lane] = pf.rec; else L.trec[lane - 32] = pf.rec;
   wsync();
@@ -1181,6 +1195,7 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
     if (left_av) left_av = lm.slice_id() == sid;
     if (top_av) top_av = tm.slice_id() == sid;
   }
+  if (!early_wait) wait_row_above (prog_above, need_above, mby > 0);
   // neighbours' filtered samples: left 4 columns carried from the previous step, top rows from `fline`
   if (mbx > 0) {
     if (lane < 20) * (LDS uint32_t*)&T[tY (lane - 4, -4)] = L.lfY[lane];
@@ -1405,16 +1420,12 @@ recon_chain_kernel (const lh264_frame_job_t* __restrict__ jobs, const int32_t* _
       const int xi = x & 63;
       const bool pub_line = row + 1 < F.mb_h && (xi == 0 || xi >= 62 || ((below >> (xi - 1)) & 7) != 0);
       const bool pub_left = x + 1 < F.mb_w && (uni ((int)nx.rec) & LH264_MB_INTRA) != 0;
-      if (row > 0) {
-        const int need = (jprev << 12) | min (x + 2, F.mb_w);
-        while ((int) (progress[wprev] - need) < 0) __builtin_amdgcn_s_sleep (1);
-        wsync();
-      }
+      const int need = (jprev << 12) | min (x + 2, F.mb_w);
       STAMP (8);
 #ifdef LH264_STAMP
-      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, pub_line, pub_left, lane, st_t0, st_acc);
+      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, pub_line, pub_left, lane, &progress[wprev], need, st_t0, st_acc);
 #else
-      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, pub_line, pub_left, lane);
+      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, pub_line, pub_left, lane, &progress[wprev], need);
 #endif
       if (lane == 0) progress[wave] = (jw << 12) | (x + 1);
       pf = nx;
