@@ -21,12 +21,12 @@ __global__ void recon_chain_kernel (const lh264_frame_job_t* jobs, const int32_t
 __global__ void ctx_nnz_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
 __global__ void ctx_inherit_chain_kernel (const lh264_ctx_job_t* jobs, const int32_t* chain_first, int n_chains);
 __global__ void ctx_symbols_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
-__global__ void coder_jobs_kernel (const lh264_code_job_t* jobs, const int32_t* chain_first, int n_jobs, int n_chains, uint32_t* jobmb0, uint32_t* job_chain, uint32_t* chain_info);
-__global__ void coder_count_kernel (const lh264_code_job_t* jobs, const uint32_t* jobmb0, const uint32_t* job_chain, int n_jobs, int blocks_per_job, uint16_t* cnt, uint32_t* chain_info);
-__global__ void coder_scan_kernel (const uint32_t* jobmb0, const int32_t* chain_first, const uint16_t* cnt, uint32_t* doff, uint32_t* chain_info, int n_chains);
+__global__ void coder_jobs_kernel (const lh264_code_job_t* jobs, const int32_t* chain_first, int n_jobs, int n_chains, uint32_t* seg0, uint32_t* job_chain, uint32_t* chain_info);
+__global__ void coder_count_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, int n_jobs, uint32_t* seg_cnt);
+__global__ void coder_scan_kernel (const uint32_t* seg0, const int32_t* chain_first, const uint32_t* seg_cnt, uint32_t* seg_doff, uint32_t* chain_info, int n_chains);
 __global__ void coder_bases_kernel (uint32_t* chain_info, int n_chains, unsigned long long* totals);
-__global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* jobmb0, const uint32_t* job_chain, int n_jobs,
-                                   int blocks_per_job, const uint32_t* doff, const uint32_t* chain_info, uint64_t* D);
+__global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* job_chain, int n_jobs,
+                                   const uint32_t* seg_doff, const uint32_t* chain_info, uint64_t* D);
 __global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint64_t* D, uint16_t* Q, int n_chains);
 __global__ void coder_code_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, const uint16_t* Q, int n_chains, int groups);
 __global__ void coder_status_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, int n_chains);
@@ -209,22 +209,23 @@ int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_fi
   std::lock_guard<std::mutex> lock (W.mu);
   hipStream_t st = (hipStream_t)stream;
   if (!W.totals_host) HIPCHK (hipHostMalloc ((void**)&W.totals_host, 2 * sizeof (unsigned long long), hipHostMallocDefault));
-  // small tables
-  const size_t o_jobmb0 = 0, o_jobchain = up256 ((size_t) (n_jobs + 1) * 4), o_info = o_jobchain + up256 ((size_t) (n_jobs + 1) * 4),
+  // small tables.  A picture of n macroblocks is cut into ceil (n / LH264_CODER_SEG_MBS) segments
+  const size_t seg_bound = (size_t)total_mbs / LH264_CODER_SEG_MBS + (size_t)n_jobs + 1;
+  const size_t o_seg0 = 0, o_jobchain = up256 ((size_t) (n_jobs + 1) * 4), o_info = o_jobchain + up256 ((size_t) (n_jobs + 1) * 4),
                o_totals = o_info + up256 ((size_t)n_chains * LH264_CODER_INFO_WORDS * 4), o_doff = o_totals + 256,
-               o_cnt = o_doff + up256 ((size_t)total_mbs * 4 + 4), small_need = o_cnt + up256 ((size_t)total_mbs * LH264_CODER_CNT_STRIDE * 2 + 2);
+               o_cnt = o_doff + up256 (seg_bound * 4 + 4), small_need = o_cnt + up256 (seg_bound * LH264_CODER_CNT_STRIDE * 4 + 4);
   if (int rc = grow (&W.small, &W.small_cap, small_need)) return rc;
   uint8_t* sm = (uint8_t*)W.small;
-  uint32_t* jobmb0 = (uint32_t*) (sm + o_jobmb0); uint32_t* job_chain = (uint32_t*) (sm + o_jobchain); uint32_t* info = (uint32_t*) (sm + o_info);
-  unsigned long long* totals = (unsigned long long*) (sm + o_totals); uint32_t* doff = (uint32_t*) (sm + o_doff); uint16_t* cnt = (uint16_t*) (sm + o_cnt);
-  const int bpj = (max_mbs_per_frame + 3) / 4;
-  hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, jobmb0, job_chain, info);
+  uint32_t* seg0 = (uint32_t*) (sm + o_seg0); uint32_t* job_chain = (uint32_t*) (sm + o_jobchain); uint32_t* info = (uint32_t*) (sm + o_info);
+  unsigned long long* totals = (unsigned long long*) (sm + o_totals); uint32_t* seg_doff = (uint32_t*) (sm + o_doff); uint32_t* seg_cnt = (uint32_t*) (sm + o_cnt);
+  (void)max_mbs_per_frame;
+  hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, seg0, job_chain, info);
   HIPCHK (hipGetLastError());
   if (n_jobs > 0 && total_mbs > 0) {
-    hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, jobmb0, job_chain, n_jobs, bpj, cnt, info);
+    hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, n_jobs, seg_cnt);
     HIPCHK (hipGetLastError());
   }
-  hipLaunchKernelGGL (lh264::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, jobmb0, chain_first_dev, cnt, doff, info, n_chains);
+  hipLaunchKernelGGL (lh264::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_cnt, seg_doff, info, n_chains);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_bases_kernel, dim3 (1), dim3 (1024), 0, st, info, n_chains, totals);
   HIPCHK (hipGetLastError());
@@ -236,7 +237,7 @@ int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_fi
   if (int rc = grow (&W.big, &W.big_cap, o_q + (size_t)n_q * 2 + 256)) return rc;
   uint64_t* D = (uint64_t*)W.big; uint16_t* Q = (uint16_t*) ((uint8_t*)W.big + o_q);
   if (n_jobs > 0 && total_mbs > 0) {
-    hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, jobmb0, job_chain, n_jobs, bpj, doff, info, D);
+    hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, job_chain, n_jobs, seg_doff, info, D);
     HIPCHK (hipGetLastError());
   }
   hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 (n_chains), dim3 (LH264_CODER_RESOLVE_THREADS), 0, st, streams_dev, info, D, Q, n_chains);

@@ -3,8 +3,10 @@
 #define LH264_CODER_INTERNAL_H_
 #include "../../include/lh264.h"
 
-// per-macroblock decision counts: [0 .. LH264_N_TAG_SLOTS-1] per tag slot (bit 15: the macroblock brings the tag's stream into
-// existence), [LH264_N_TAG_SLOTS] all decisions of the macroblock
+// the parallel binarisation works on segments of at most this many consecutive macroblocks of a picture (<= 256: one thread each)
+#define LH264_CODER_SEG_MBS 128
+// per-segment decision counts (32-bit): [0 .. LH264_N_TAG_SLOTS-1] per tag slot (bit 31: the segment brings the tag's stream into
+// existence), [LH264_N_TAG_SLOTS] all decisions of the segment
 #define LH264_CODER_CNT_STRIDE (LH264_N_TAG_SLOTS + 1)
 
 // per-stream record (32-bit words)

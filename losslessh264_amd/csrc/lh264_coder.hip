@@ -235,36 +235,6 @@ __device__ __forceinline__ SymCount sym_count (uint32_t prior, int value, int ki
   return c;
 }
 
-// ---- the symbols of one macroblock in coding order: the host list with the coefficient symbols in place of the marker ---------
-struct MbSyms {
-  const GLB uint64_t* hs; const GLB uint64_t* cs;
-  int p, mc, hskip, total;        // marker position (or the list's length), coefficient symbols, 1 if there is a marker
-};
-__device__ __forceinline__ MbSyms mb_syms (const lh264_code_job_t* J, int k, int lane) {
-  MbSyms m;
-  const GLB uint32_t* off = glb<const uint32_t> (J->syn_off_dev);
-  const uint32_t o0v = off[k], o1v = off[k + 1], mcv = glb<const uint16_t> (J->ctx_n_syms_dev)[k];       // one round trip for the three
-  const uint32_t o0 = (uint32_t)uniform ((int)o0v), o1 = (uint32_t)uniform ((int)o1v);
-  const int nh = (int) (o1 - o0);
-  m.hs = glb<const uint64_t> (J->syn_syms_dev) + o0;
-  m.cs = glb<const uint64_t> (J->ctx_syms_dev) + (size_t)k * LH264_CTX_MAX_SYMS;
-  m.p = nh; m.hskip = 0; m.mc = 0;
-  for (int c = 0; c < nh; c += 64) {
-    const uint64_t hv = c + lane < nh ? m.hs[c + lane] : 0ull;
-    const unsigned long long spl = __ballot (c + lane < nh && ((hv >> 48) & 0xffull) == (unsigned long long)LH264_SYM_SPLICE);
-    if (spl) { m.p = c + __ffsll ((long long)spl) - 1; m.hskip = 1; break; }
-  }
-  if (m.hskip) m.mc = uniform ((int)mcv);
-  m.total = nh - m.hskip + m.mc;
-  return m;
-}
-__device__ __forceinline__ uint64_t mb_sym_at (const MbSyms& m, int i) {
-  if (i < m.p) return m.hs[i];
-  if (i < m.p + m.mc) return m.cs[i - m.p];
-  return m.hs[i - m.mc + m.hskip];
-}
-
-// ---- sinks -----------------------------------------------------------------------------------------------------------------
 // a decision word (64 bits): the low dword is the key of the prior's cell (LH264_PRIOR form; 0 for a raw bit), the high dword
 // bits 0..3 the place in the cell, bit 4 the bit, bits 5..10 the tag slot, bit 31 "raw bit" (coded with TEST_PROB)
 struct EmitSink {
@@ -278,10 +248,77 @@ struct EmitSink {
   }
 };
 
-// ---- kernel 0: where each picture's macroblocks start in the flat per-macroblock tables; which stream a picture belongs to -----
+// ---- segments: the unit of the parallel binarisation -----------------------------------------------------------------------------
+// A segment = up to CODER_SEG consecutive macroblocks of one picture.  Its symbols in coding order are, macroblock after macroblock,
+// the host list with the coefficient symbols in place of the marker; the workgroup of a segment lays that order out once in LDS
+// (where each macroblock's symbols start, where its marker is) and then walks the symbols 64 per wave step whatever macroblock they
+// belong to - a wave per macroblock would idle most lanes on the many macroblocks with a handful of symbols.
+#define CODER_SEG LH264_CODER_SEG_MBS
+struct SegLds {
+  uint32_t hoff[CODER_SEG + 1];      // host symbols of macroblock k start here (offsets into the picture's list)
+  uint32_t sbase[CODER_SEG + 1];     // symbols of the segment before macroblock k, in coding order
+  uint16_t mc[CODER_SEG];            // coefficient symbols of macroblock k
+  uint16_t p[CODER_SEG];             // position of the marker in macroblock k's host list (0xffff: none)
+  uint32_t wsum[4];
+  uint32_t cnt[4][LH264_N_TAG_SLOTS + 2];      // per wave (the symbols of a step mostly count towards the same few tags)
+};
+struct Seg { const lh264_code_job_t* J; int job, k0, n; uint32_t total; };
+// which picture and which macroblocks block `b` works on: seg0[] = segments before picture j
+__device__ __forceinline__ bool seg_locate (const lh264_code_job_t* jobs, const uint32_t* seg0, int n_jobs, uint32_t b, Seg& S) {
+  if (b >= seg0[n_jobs]) return false;
+  uint32_t lo = 0, hi = (uint32_t)n_jobs;              // largest j with seg0[j] <= b
+  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (seg0[mid] <= b) lo = mid; else hi = mid; }
+  S.job = (int)lo; S.J = jobs + lo;
+  S.k0 = (int) (b - seg0[lo]) * CODER_SEG;
+  S.n = min (CODER_SEG, S.J->n_mbs - S.k0);
+  return S.n > 0;
+}
+// lay the segment out (all 256 threads); afterwards L.sbase[S.n] = S.total symbols
+__device__ __forceinline__ void seg_layout (LDS SegLds& L, Seg& S, int tid) {
+  const GLB uint32_t* off = glb<const uint32_t> (S.J->syn_off_dev) + S.k0;
+  const GLB uint16_t* cn = glb<const uint16_t> (S.J->ctx_n_syms_dev) + S.k0;
+  if (tid <= S.n) L.hoff[tid] = off[tid];
+  if (tid < S.n) { L.mc[tid] = cn[tid]; L.p[tid] = 0xffffu; }
+  __syncthreads();
+  // the markers: every host symbol of the segment is looked at once
+  const GLB uint64_t* hs = glb<const uint64_t> (S.J->syn_syms_dev);
+  const uint32_t h0 = L.hoff[0], h1 = L.hoff[S.n];
+  for (uint32_t h = h0 + (uint32_t)tid; h < h1; h += 256u) {
+    if (((hs[h] >> 48) & 0xffull) == (unsigned long long)LH264_SYM_SPLICE) {
+      uint32_t lo = 0, hi = (uint32_t)S.n;               // the macroblock whose list holds position h
+      while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (L.hoff[mid] <= h) lo = mid; else hi = mid; }
+      L.p[lo] = (uint16_t) (h - L.hoff[lo]);
+    }
+  }
+  __syncthreads();
+  // symbols per macroblock, running sum (the segment has at most 256 macroblocks: one per thread)
+  uint32_t v = 0;
+  if (tid < S.n) { const uint32_t nh = L.hoff[tid + 1] - L.hoff[tid]; v = L.p[tid] != 0xffffu ? nh - 1u + L.mc[tid] : nh; }
+  const uint32_t incl = (uint32_t)wave_scan_add ((int)v);
+  if ((tid & 63) == 63) L.wsum[tid >> 6] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int w = 0; w < (tid >> 6); w++) before += L.wsum[w];
+  if (tid < S.n) L.sbase[tid] = before + incl - v;
+  if (tid == 255) L.sbase[S.n] = before + incl;
+  __syncthreads();
+  S.total = L.sbase[S.n];
+}
+// symbol s of the segment (coding order)
+__device__ __forceinline__ uint64_t seg_symbol (const LDS SegLds& L, const Seg& S, uint32_t s) {
+  uint32_t lo = 0, hi = (uint32_t)S.n;                   // the macroblock that holds symbol s
+  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (L.sbase[mid] <= s) lo = mid; else hi = mid; }
+  const uint32_t i = s - L.sbase[lo], p = L.p[lo], mc = p != 0xffffu ? L.mc[lo] : 0u;
+  const GLB uint64_t* hs = glb<const uint64_t> (S.J->syn_syms_dev) + L.hoff[lo];
+  if (i < p || p == 0xffffu) return hs[i];
+  if (i < p + mc) return glb<const uint64_t> (S.J->ctx_syms_dev)[(size_t) (S.k0 + (int)lo) * LH264_CTX_MAX_SYMS + (i - p)];
+  return hs[i - mc + 1u];
+}
+
+// ---- kernel 0: segments before each picture; which stream a picture belongs to ----------------------------------------------------
 __global__ void __launch_bounds__ (1024)
 coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __restrict__ chain_first, int n_jobs, int n_chains,
-                   uint32_t* __restrict__ jobmb0, uint32_t* __restrict__ job_chain, uint32_t* __restrict__ chain_info) {
+                   uint32_t* __restrict__ seg0, uint32_t* __restrict__ job_chain, uint32_t* __restrict__ chain_info) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -289,18 +326,18 @@ coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __r
   __syncthreads();
   for (int j0 = 0; j0 < n_jobs; j0 += 1024) {
     const int j = j0 + tid;
-    const int v = j < n_jobs ? jobs[j].n_mbs : 0;
+    const int v = j < n_jobs ? (max (jobs[j].n_mbs, 0) + CODER_SEG - 1) / CODER_SEG : 0;
     const int incl = wave_scan_add (v);
     if (lane == 63) wsum[wave] = (uint32_t)incl;
     __syncthreads();
     uint32_t before = carry;
     for (int w = 0; w < wave; w++) before += wsum[w];
-    if (j < n_jobs) jobmb0[j] = before + (uint32_t) (incl - v);
+    if (j < n_jobs) seg0[j] = before + (uint32_t) (incl - v);
     __syncthreads();
     if (tid == 1023) carry = before + (uint32_t)incl;
     __syncthreads();
   }
-  if (tid == 0) jobmb0[n_jobs] = carry;
+  if (tid == 0) seg0[n_jobs] = carry;
   for (int c = tid; c < n_chains; c += 1024) {
     for (int j = chain_first[c]; j < chain_first[c + 1]; j++) job_chain[j] = (uint32_t)c;
     chain_info[(size_t)c * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS] = 0;
@@ -308,72 +345,58 @@ coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __r
   }
 }
 
-// ---- kernel 1: decisions per tag of every macroblock ------------------------------------------------------------------------
+// ---- kernel 1: decisions per tag of every segment ---------------------------------------------------------------------------------
+// seg_cnt[segment][0 .. LH264_N_TAG_SLOTS-1] decisions per tag slot (bit 31: the segment brings the tag's stream into existence),
+// [LH264_N_TAG_SLOTS] all decisions
 __global__ void __launch_bounds__ (256)
-coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ jobmb0, const uint32_t* __restrict__ job_chain,
-                    int n_jobs, int blocks_per_job, uint16_t* __restrict__ cnt, uint32_t* __restrict__ chain_info) {
-  __shared__ uint32_t lc[4][LH264_CODER_CNT_STRIDE + 1];
-  const int ji = blockIdx.x / blocks_per_job;
-  if (ji >= n_jobs) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const lh264_code_job_t* J = jobs + ji;
-  for (int k = (blockIdx.x % blocks_per_job) * 4 + wave; k < J->n_mbs; k += blocks_per_job * 4) {
-    if (lane < LH264_CODER_CNT_STRIDE + 1) lc[wave][lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    const MbSyms m = mb_syms (J, k, lane);
-    bool bad = false;
-    for (int c = 0; c < m.total; c += 64) {
-      const int i = c + lane;
-      if (i < m.total) {
-        const uint64_t sym = mb_sym_at (m, i);
-        const uint32_t hi = (uint32_t) (sym >> 32);
-        const SymCount s = sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24));
-        if (s.s0 >= 0) atomicAdd (&lc[wave][s.s0], (uint32_t)s.n0);
-        if (s.s1 >= 0) atomicAdd (&lc[wave][s.s1], (uint32_t)s.n1);
-        if (s.s2 >= 0) atomicAdd (&lc[wave][s.s2], (uint32_t)s.n2);
-        if (s.s3 >= 0) atomicAdd (&lc[wave][s.s3], (uint32_t)s.n3);
-        if (s.tch >= 0) atomicOr (&lc[wave][s.tch], 0x80000000u);
-        atomicAdd (&lc[wave][LH264_N_TAG_SLOTS], (uint32_t)s.n);
-      }
+coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, int n_jobs, uint32_t* __restrict__ seg_cnt) {
+  __shared__ SegLds Lg;
+  LDS SegLds& L = * (LDS SegLds*) (uintptr_t) (uint32_t) (uintptr_t)&Lg;
+  Seg S;
+  if (!seg_locate (jobs, seg0, n_jobs, blockIdx.x, S)) return;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 4 * (LH264_N_TAG_SLOTS + 2); i += 256) (&L.cnt[0][0])[i] = 0;
+  seg_layout (L, S, tid);
+  LDS uint32_t* cw = L.cnt[tid >> 6];
+  uint32_t tot = 0;
+  for (uint32_t s0 = 0; s0 < S.total; s0 += 256u) {
+    const uint32_t s = s0 + (uint32_t)tid;
+    if (s < S.total) {
+      const uint64_t sym = seg_symbol (L, S, s);
+      const uint32_t hi = (uint32_t) (sym >> 32);
+      const SymCount c = sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24));
+      if (c.s0 >= 0) __hip_atomic_fetch_add (&cw[c.s0], (uint32_t)c.n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (c.s1 >= 0) __hip_atomic_fetch_add (&cw[c.s1], (uint32_t)c.n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (c.s2 >= 0) __hip_atomic_fetch_add (&cw[c.s2], (uint32_t)c.n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (c.s3 >= 0) __hip_atomic_fetch_add (&cw[c.s3], (uint32_t)c.n3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (c.tch >= 0) __hip_atomic_fetch_or (&cw[c.tch], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      tot += (uint32_t)c.n;
     }
-    __builtin_amdgcn_wave_barrier();
-    const size_t g = (size_t)jobmb0[ji] + (size_t)k;
-    if (lane <= LH264_N_TAG_SLOTS) {
-      const uint32_t v = lc[wave][lane];
-      const uint32_t n = v & 0x7fffffffu;
-      bad = bad || n > (lane < LH264_N_TAG_SLOTS ? 0x7fffu : 0xffffu);
-      cnt[g * LH264_CODER_CNT_STRIDE + lane] = (uint16_t) (lane < LH264_N_TAG_SLOTS ? ((n & 0x7fffu) | (v >> 31) << 15) : n);
-    }
-    if (__ballot (bad) && lane == 0) atomicOr (&chain_info[(size_t)job_chain[ji] * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_COUNT);
-    __builtin_amdgcn_wave_barrier();
+  }
+  tot = (uint32_t)__builtin_amdgcn_readlane (wave_scan_add ((int)tot), 63);
+  if ((tid & 63) == 0) cw[LH264_N_TAG_SLOTS] = tot;
+  __syncthreads();
+  if (tid <= LH264_N_TAG_SLOTS) {
+    const uint32_t a = L.cnt[0][tid], b = L.cnt[1][tid], c = L.cnt[2][tid], d = L.cnt[3][tid];
+    seg_cnt[(size_t)blockIdx.x * LH264_CODER_CNT_STRIDE + tid] = ((a + b + c + d) & 0x7fffffffu) | ((a | b | c | d) & 0x80000000u);
   }
 }
 
-// ---- kernel 2: per stream, the start of each macroblock's decisions and the size of every tag's list ---------------------------
+// ---- kernel 2: per stream, where each segment's decisions start and the size of every tag's list ---------------------------------------
 __global__ void __launch_bounds__ (64)
-coder_scan_kernel (const uint32_t* __restrict__ jobmb0, const int32_t* __restrict__ chain_first, const uint16_t* __restrict__ cnt,
-                   uint32_t* __restrict__ doff, uint32_t* __restrict__ chain_info, int n_chains) {
+coder_scan_kernel (const uint32_t* __restrict__ seg0, const int32_t* __restrict__ chain_first, const uint32_t* __restrict__ seg_cnt,
+                   uint32_t* __restrict__ seg_doff, uint32_t* __restrict__ chain_info, int n_chains) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c >= n_chains) return;
-  const size_t m0 = jobmb0[chain_first[c]], m1 = jobmb0[chain_first[c + 1]];
+  const size_t m0 = seg0[chain_first[c]], m1 = seg0[chain_first[c + 1]];
   uint32_t acc = 0, touched = 0;
+  bool big = false;
   const int t = lane <= LH264_N_TAG_SLOTS ? lane : LH264_N_TAG_SLOTS;
-  const GLB uint16_t* p = glb<const uint16_t> (cnt) + t;
-  size_t mb = m0;
-  for (; mb + 32 <= m1; mb += 32) {              // 32 reads in flight per lane: the walk is bound by memory latency
-    uint32_t v[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) v[i] = p[(mb + i) * LH264_CODER_CNT_STRIDE];
-#pragma unroll
-    for (int i = 0; i < 32; i++) {
-      if (lane == LH264_N_TAG_SLOTS) { doff[mb + i] = acc; acc += v[i]; }
-      else { acc += v[i] & 0x7fffu; touched |= v[i] >> 15; }
-    }
-  }
-  for (; mb < m1; mb++) {
-    const uint32_t v = p[mb * LH264_CODER_CNT_STRIDE];
-    if (lane == LH264_N_TAG_SLOTS) { doff[mb] = acc; acc += v; }
-    else { acc += v & 0x7fffu; touched |= v >> 15; }
+  const GLB uint32_t* p = glb<const uint32_t> (seg_cnt) + t;
+  for (size_t g = m0; g < m1; g++) {
+    const uint32_t v = p[g * LH264_CODER_CNT_STRIDE];
+    if (lane == LH264_N_TAG_SLOTS) { seg_doff[g] = acc; big = big || acc + v < acc; acc += v; }
+    else { acc += v & 0x7fffffffu; touched |= v >> 31; }
   }
   uint32_t* I = chain_info + (size_t)c * LH264_CODER_INFO_WORDS;
   // tag lists are padded to 8 entries (16 bytes): the coding kernel reads them 16 bytes at a time
@@ -383,6 +406,7 @@ coder_scan_kernel (const uint32_t* __restrict__ jobmb0, const int32_t* __restric
   const unsigned long long tm = __ballot (lane < LH264_N_TAG_SLOTS && touched != 0);
   if (lane == LH264_N_TAG_SLOTS) { I[LH264_CODER_INFO_NDEC] = acc; I[LH264_CODER_INFO_TOUCH] = (uint32_t)tm; I[LH264_CODER_INFO_TOUCH + 1] = (uint32_t) (tm >> 32); }
   if (lane == 63) I[LH264_CODER_INFO_NQ] = incl;
+  if (__ballot (big) && lane == 0) atomicOr (&I[LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_COUNT);      // more than 2^32 decisions in a stream
 }
 
 // ---- kernel 3: where each stream's decision words and tag lists start (prefix over the streams); the totals for the host -------
@@ -421,36 +445,49 @@ coder_bases_kernel (uint32_t* __restrict__ chain_info, int n_chains, unsigned lo
 }
 
 // ---- kernel 4: the decision words, in coding order -------------------------------------------------------------------------
+// The four waves of a segment's workgroup take a quarter of its symbols each: first how many decisions the quarter makes, then, behind
+// a barrier, the words from where the quarters before it end.
 __global__ void __launch_bounds__ (256)
-coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ jobmb0, const uint32_t* __restrict__ job_chain,
-                   int n_jobs, int blocks_per_job, const uint32_t* __restrict__ doff, const uint32_t* __restrict__ chain_info,
-                   uint64_t* __restrict__ D) {
-  const int ji = blockIdx.x / blocks_per_job;
-  if (ji >= n_jobs) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const lh264_code_job_t* J = jobs + ji;
-  const uint32_t chain = job_chain[ji];
-  const uint32_t* I = chain_info + (size_t)chain * LH264_CODER_INFO_WORDS;
-  const unsigned long long dbase = (unsigned long long)I[LH264_CODER_INFO_DBASE] | (unsigned long long)I[LH264_CODER_INFO_DBASE + 1] << 32;
-  for (int k = (blockIdx.x % blocks_per_job) * 4 + wave; k < J->n_mbs; k += blocks_per_job * 4) {
-    const MbSyms m = mb_syms (J, k, lane);
-    uint32_t running = doff[(size_t)jobmb0[ji] + (size_t)k];
-    for (int c = 0; c < m.total; c += 64) {
-      const int i = c + lane;
-      uint64_t sym = 0; uint32_t hi = 0;
-      struct { int n; } ts; ts.n = 0;
-      if (i < m.total) {
-        sym = mb_sym_at (m, i);
-        hi = (uint32_t) (sym >> 32);
-        ts.n = sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24)).n;
-      }
-      const int incl = wave_scan_add (ts.n);
-      if (i < m.total && ts.n > 0) {
-        EmitSink es; es.D = glb<uint64_t> (D) + dbase; es.pos = running + (uint32_t) (incl - ts.n); es.key = 0;
-        binarize (es, (uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24));
-      }
-      running += (uint32_t)__builtin_amdgcn_readlane (incl, 63);
+coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ job_chain,
+                   int n_jobs, const uint32_t* __restrict__ seg_doff, const uint32_t* __restrict__ chain_info, uint64_t* __restrict__ D) {
+  __shared__ SegLds Lg;
+  __shared__ uint32_t qtot[4];
+  LDS SegLds& L = * (LDS SegLds*) (uintptr_t) (uint32_t) (uintptr_t)&Lg;
+  Seg S;
+  if (!seg_locate (jobs, seg0, n_jobs, blockIdx.x, S)) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  seg_layout (L, S, tid);
+  const uint32_t* I = chain_info + (size_t)job_chain[S.job] * LH264_CODER_INFO_WORDS;
+  const unsigned long long dbase = ((unsigned long long)I[LH264_CODER_INFO_DBASE] | (unsigned long long)I[LH264_CODER_INFO_DBASE + 1] << 32) + seg_doff[blockIdx.x];
+  const uint32_t per = (S.total + 3u) >> 2, s_lo = min ((uint32_t)wave * per, S.total), s_hi = min (s_lo + per, S.total);
+  uint32_t mine = 0;
+  for (uint32_t s0 = s_lo; s0 < s_hi; s0 += 64u) {
+    const uint32_t s = s0 + (uint32_t)lane;
+    if (s < s_hi) {
+      const uint64_t sym = seg_symbol (L, S, s);
+      const uint32_t hi = (uint32_t) (sym >> 32);
+      mine += (uint32_t)sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24)).n;
     }
+  }
+  const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane (wave_scan_add ((int)mine), 63);
+  if (lane == 0) qtot[wave] = wtot;
+  __syncthreads();
+  uint32_t running = 0;
+  for (int w = 0; w < wave; w++) running += qtot[w];
+  for (uint32_t s0 = s_lo; s0 < s_hi; s0 += 64u) {
+    const uint32_t s = s0 + (uint32_t)lane;
+    uint64_t sym = 0; uint32_t hi = 0; int n = 0;
+    if (s < s_hi) {
+      sym = seg_symbol (L, S, s);
+      hi = (uint32_t) (sym >> 32);
+      n = sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24)).n;
+    }
+    const int incl = wave_scan_add (n);
+    if (n > 0) {
+      EmitSink es; es.D = glb<uint64_t> (D) + dbase; es.pos = running + (uint32_t) (incl - n); es.key = 0;
+      binarize (es, (uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24));
+    }
+    running += (uint32_t)__builtin_amdgcn_readlane (incl, 63);
   }
 }
 
