@@ -276,11 +276,13 @@ def main():
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes from the
     # committed rocprofv3 --pmc passes over the same launch (profiles/traffic.json), corrected as the guide prescribes
-    traffic = None
+    traffic = coder_traffic = None
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["recon_chain_kernel"]
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        t = tj["recon_chain_kernel"]
         if t["streams"] == n_local and args.config == 1:
             traffic = (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
+            coder_traffic = sum((2.0 * v["fetch_size_kb"] + v["write_size_kb"]) * 1024.0 for k, v in tj.items() if k.startswith("coder_"))
     except (OSError, KeyError, ValueError):
         pass
 
@@ -394,7 +396,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "recon_chain_kernel", "kernel_ms": k_ms["recon"], "algorithmic_bytes_per_launch": alg_bytes,
                          "coder_stage": {"bound": "hbm", "achieved": coder_bytes / (k_ms["coder"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": coder_bytes / (k_ms["coder"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": k_ms["coder"], "algorithmic_bytes": coder_bytes,
+                                         "frac": coder_bytes / (k_ms["coder"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": k_ms["coder"], "algorithmic_bytes": coder_bytes, "traffic": coder_traffic,
                                          "note": "symbols read twice + 8-byte decision words and 2-byte list entries written and read once + output; "
                                                  "the stage is bound by two serial chains (per adaptive probability, per tag), not by HBM"}},
         }
