@@ -1422,10 +1422,19 @@ recon_chain_kernel (const lh264_frame_job_t* __restrict__ jobs, const int32_t* _
       const bool pub_left = x + 1 < F.mb_w && (uni ((int)nx.rec) & LH264_MB_INTRA) != 0;
       const int need = (jprev << 12) | min (x + 2, F.mb_w);
       STAMP (8);
-#ifdef LH264_STAMP
-      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, pub_line, pub_left, lane, &progress[wprev], need, st_t0, st_acc);
+      // The lane index goes in opaque: otherwise every lane-dependent address and mask of the macroblock's steps is hoisted out of
+      // this loop, and at 128 registers 47 of them live in scratch (12.8 KB per wave, more than the L2 holds for a full chip: the
+      // reloads were most of the kernel's HBM traffic).  Recomputing them per macroblock costs a few dozen VALU instructions.
+#ifndef LH264_HOIST_LANE
+      int lane_mb = lane;
+      asm volatile ("" : "+v" (lane_mb));
 #else
-      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, pub_line, pub_left, lane, &progress[wprev], need);
+      const int lane_mb = lane;
+#endif
+#ifdef LH264_STAMP
+      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, pub_line, pub_left, lane_mb, &progress[wprev], need, st_t0, st_acc);
+#else
+      process_mb (F, L, G, B, pf, x, row, x & 1, slc_id, pub_line, pub_left, lane_mb, &progress[wprev], need);
 #endif
       if (lane == 0) progress[wave] = (jw << 12) | (x + 1);
       pf = nx;
