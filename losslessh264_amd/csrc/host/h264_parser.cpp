@@ -195,18 +195,22 @@ struct Parser::Impl {
   Symbolizer symbolizer;
   int last_hdr_bits = -1; bool last_cabac = false;
   int16_t no_coef[384];                                  // where the dequantised coefficients go when nobody wants them
-  alignas (8) int16_t lev_scratch[384];                  // sparse mode: the macroblock in hand, turned into list entries when it is done
+  alignas (8) int16_t lev_scratch[384] = {};                  // sparse mode: the macroblock in hand, turned into list entries when it is done
   // a coded macroblock is done: note whether it has any nonzero level; in sparse mode list them (picture-relative index << 16 | value)
+  uint32_t lev_mask = 0;                                 // sparse mode: the 16-coefficient blocks of lev_scratch written for the macroblock in hand
   void finish_levels (int k) {
-    const int16_t* lv = self->sparse_levels_ ? lev_scratch : &cur->levels[(size_t)k * 384];
     bool any = false;
-    for (int i = 0; i < 96; i++) {
-      uint64_t q;
-      memcpy (&q, lv + 4 * i, 8);
-      if (!q) continue;
-      any = true;
-      if (!self->sparse_levels_) break;
-      for (int j = 0; j < 4; j++) { const int16_t v = lv[4 * i + j]; if (v) cur->sparse.push_back (((uint64_t) ((size_t)k * 384 + 4 * i + j) << 16) | (uint16_t)v); }
+    if (self->sparse_levels_) {
+      // only the blocks that were written are looked at, and they are zero again afterwards
+      for (uint32_t msk = lev_mask; msk; msk &= msk - 1) {
+        int16_t* b = lev_scratch + 16 * __builtin_ctz (msk);
+        const size_t at = (size_t)k * 384 + (size_t) (b - lev_scratch);
+        for (int j = 0; j < 16; j++) if (b[j]) { any = true; cur->sparse.push_back (((uint64_t) (at + j) << 16) | (uint16_t)b[j]); b[j] = 0; }
+      }
+      lev_mask = 0;
+    } else {
+      const int16_t* lv = &cur->levels[(size_t)k * 384];
+      for (int i = 0; i < 96 && !any; i++) { uint64_t q; memcpy (&q, lv + 4 * i, 8); any = q != 0; }
     }
     cur->lev_nonzero[k] = any ? 1 : 0;
   }       // the slice NAL just handled: header length in bits, entropy mode
@@ -843,7 +847,7 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
   for (int i = 0; i < 4; i++) { s.ref[i] = -1; m.ref_idx[i] = -1; }
   int16_t* coef = self->want_coeffs_ ? &cur->coeffs[(size_t)k * 384] : no_coef;
   int16_t* lev = self->sparse_levels_ ? lev_scratch : &cur->levels[(size_t)k * 384];
-  if ((self->lazy_levels_ || self->sparse_levels_) && !is_skip) memset (lev, 0, 768);
+  if (self->lazy_levels_ && !self->sparse_levels_ && !is_skip) memset (lev, 0, 768);     // (the sparse scratch is left zero by finish_levels)
   const bool use_sl = S.scaling_matrix_present || P.scaling_matrix_present;
   auto set_qp = [&] (int qp) {
     m.qp_y = (uint8_t)qp;
@@ -1018,7 +1022,7 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
     if (residual_block (br, luma_nC (0, 0), 16, lv) < 0) { fail ("CAVLC error (I16 DC)"); return false; }
     for (int i = 0; i < 16; i++) if (lv[i]) {
         const int r = kZigzag4x4[i], zb = xy2z (r & 3, r >> 2);
-        coef[zb * 16] = lev[zb * 16] = (int16_t)lv[i];           // dequantised by the DC transform on the device
+        coef[zb * 16] = lev[zb * 16] = (int16_t)lv[i]; lev_mask |= 1u << zb;           // dequantised by the DC transform on the device
       }
   }
   for (int i8 = 0; i8 < 4; i8++) {
@@ -1032,11 +1036,11 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
       for (int i = 0; i < maxc; i++) if (lv[i]) {
           if (t8) {
             const int pos = kZigzag8x8[4 * i + j];
-            lev[i8 * 64 + pos] = (int16_t)lv[i];
+            { const int li_ = i8 * 64 + pos; lev[li_] = (int16_t)lv[i]; lev_mask |= 1u << (li_ >> 4); }
             coef[i8 * 64 + pos] = (int16_t)dq8 (P, use_sl, intra ? 0 : 1, qp, pos, lv[i]);
           } else {
             const int pos = kZigzag4x4[i16 ? i + 1 : i];
-            lev[z * 16 + pos] = (int16_t)lv[i];
+            { const int li_ = z * 16 + pos; lev[li_] = (int16_t)lv[i]; lev_mask |= 1u << (li_ >> 4); }
             coef[z * 16 + pos] = (int16_t)dq4 (P, use_sl, ylist, qp, pos, lv[i]);
           }
         }
@@ -1049,7 +1053,7 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
       const int qc = m.qp_c[p];
       const int d0 = kNormAdjust4x4[qc % 6][0] << (qc / 6);
       for (int i = 0; i < 4; i++) if (lv[i]) {
-          lev[256 + p * 64 + i * 16] = (int16_t)lv[i];
+          { const int li_ = 256 + p * 64 + i * 16; lev[li_] = (int16_t)lv[i]; lev_mask |= 1u << (li_ >> 4); }
           coef[256 + p * 64 + i * 16] = (int16_t) (use_sl ? (lv[i] * (P.sl4[ylist + 1 + p][0] * d0)) >> 4 : lv[i] * d0);
         }
     }
@@ -1063,7 +1067,7 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
           m.nzc[kChromaNzcIdx[p][j]] = (uint8_t)tot;
           for (int i = 0; i < 15; i++) if (lv[i]) {
               const int pos = kZigzag4x4[i + 1];
-              lev[256 + p * 64 + j * 16 + pos] = (int16_t)lv[i];
+              { const int li_ = 256 + p * 64 + j * 16 + pos; lev[li_] = (int16_t)lv[i]; lev_mask |= 1u << (li_ >> 4); }
               coef[256 + p * 64 + j * 16 + pos] = (int16_t)dq4 (P, use_sl, ylist + 1 + p, m.qp_c[p], pos, lv[i]);
             }
         }
@@ -1192,7 +1196,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
   s.skip = 0; s.pcm = 0; s.t8 = 0; s.cbp = 0; s.chroma_pred = 0; s.cbf = 0;
   int16_t* coef = self->want_coeffs_ ? &cur->coeffs[(size_t)k * 384] : no_coef;
   int16_t* lev = self->sparse_levels_ ? lev_scratch : &cur->levels[(size_t)k * 384];
-  if ((self->lazy_levels_ || self->sparse_levels_) && !is_skip) memset (lev, 0, 768);
+  if (self->lazy_levels_ && !self->sparse_levels_ && !is_skip) memset (lev, 0, 768);     // (the sparse scratch is left zero by finish_levels)
   const bool use_sl = S.scaling_matrix_present || P.scaling_matrix_present;
   const int kA = ((k % w) && mb_avail (k - 1, sid)) ? k - 1 : -1, kB = (k >= w && mb_avail (k - w, sid)) ? k - w : -1;
   auto set_qp = [&] (int qp) {
@@ -1481,7 +1485,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
     cabac_residual (cb, k, sid, 0, 0, 0, true, lv, 16);
     for (int i = 0; i < 16; i++) if (lv[i]) {
         const int r = kZigzag4x4[i], zb = xy2z (r & 3, r >> 2);
-        coef[zb * 16] = lev[zb * 16] = (int16_t)lv[i];
+        coef[zb * 16] = lev[zb * 16] = (int16_t)lv[i]; lev_mask |= 1u << zb;
       }
   }
   for (int i8 = 0; i8 < 4; i8++) {
@@ -1491,7 +1495,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
       for (int j = 0; j < 4; j++) { const int z = i8 * 4 + j; m.nzc[z2y (z) * 4 + z2x (z)] = (uint8_t)tot; s.cbf |= 1u << (z2y (z) * 4 + z2x (z)); }
       for (int i = 0; i < 64; i++) if (lv[i]) {
           const int pos = kZigzag8x8[i];
-          lev[i8 * 64 + pos] = (int16_t)lv[i];
+          { const int li_ = i8 * 64 + pos; lev[li_] = (int16_t)lv[i]; lev_mask |= 1u << (li_ >> 4); }
           coef[i8 * 64 + pos] = (int16_t)dq8 (P, use_sl, intra ? 0 : 1, qp, pos, lv[i]);
         }
       continue;
@@ -1503,7 +1507,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
       m.nzc[by * 4 + bx] = (uint8_t)tot;
       for (int i = 0; i < maxc; i++) if (lv[i]) {
           const int pos = kZigzag4x4[i16 ? i + 1 : i];
-          lev[z * 16 + pos] = (int16_t)lv[i];
+          { const int li_ = z * 16 + pos; lev[li_] = (int16_t)lv[i]; lev_mask |= 1u << (li_ >> 4); }
           coef[z * 16 + pos] = (int16_t)dq4 (P, use_sl, ylist, qp, pos, lv[i]);
         }
     }
@@ -1515,7 +1519,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
       const int qc = m.qp_c[p];
       const int d0 = kNormAdjust4x4[qc % 6][0] << (qc / 6);
       for (int i = 0; i < 4; i++) if (lv[i]) {
-          lev[256 + p * 64 + i * 16] = (int16_t)lv[i];
+          { const int li_ = 256 + p * 64 + i * 16; lev[li_] = (int16_t)lv[i]; lev_mask |= 1u << (li_ >> 4); }
           coef[256 + p * 64 + i * 16] = (int16_t) (use_sl ? (lv[i] * (P.sl4[ylist + 1 + p][0] * d0)) >> 4 : lv[i] * d0);
         }
     }
@@ -1525,7 +1529,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
           m.nzc[kChromaNzcIdx[p][j]] = (uint8_t)tot;
           for (int i = 0; i < 15; i++) if (lv[i]) {
               const int pos = kZigzag4x4[i + 1];
-              lev[256 + p * 64 + j * 16 + pos] = (int16_t)lv[i];
+              { const int li_ = 256 + p * 64 + j * 16 + pos; lev[li_] = (int16_t)lv[i]; lev_mask |= 1u << (li_ >> 4); }
               coef[256 + p * 64 + j * 16 + pos] = (int16_t)dq4 (P, use_sl, ylist + 1 + p, m.qp_c[p], pos, lv[i]);
             }
         }

@@ -985,6 +985,9 @@ __device__ LH264_PHASE void deblock_phase (LDS WaveLds& L, const LDS WgLds& G, R
   const v4u bs0 = * (const LDS v4u*)&L.bs[0], bs1 = * (const LDS v4u*)&L.bs[16];     // [edge] = 4 segment bytes
   const bool any0 = uni ((int) (bs0.x | bs0.y | bs0.z | bs0.w)) != 0, any1 = uni ((int) (bs1.x | bs1.y | bs1.z | bs1.w)) != 0;
   if ((!any0 && !any1) || lane >= 32) return;
+#ifdef LH264_ABL_BSONLY      // timing ablation only (wrong pictures): boundary strengths, no filtering
+  return;
+#endif
   const bool chroma = lane >= 16;
   const int cpl = (lane >> 3) & 1;                  // chroma plane of lanes 16..31
   const int li = chroma ? (lane & 7) : lane;        // line inside the plane
@@ -1140,7 +1143,9 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
     if (mb_type != LH264_MB_IPCM) {
       if (has_res) {
         const int dcw = sl.luma_dc_weight();
+#ifndef LH264_ABL_NORES      // timing ablation only (wrong pictures)
         residual_phase (L, pf.l, pf.c, mb_type, cbp, t8, m.qp_y(), dcw ? dcw : 16, lane);
+#endif
       } else if (intra) zero_residual (L, lane);
     }
     STAMP (2);
@@ -1164,7 +1169,9 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
       InterCtx ic;
       ic.prev_dy = F.prev_dy; ic.sy = F.sy; ic.sc = F.sc; ic.mb_w = F.mb_w; ic.mb_h = F.mb_h;
       ic.prev_base = F.prev_base; ic.prev_h = F.prev_h; ic.nw = F.nw;
+#ifndef LH264_ABL_NOINTER    // timing ablation only (wrong pictures)
       inter_phase (ic, L, G, m, sl, mb_type, mbx, mby, has_res, lane);
+#endif
     }
   } else {
     // macroblock not covered by any slice (lost data): pass the picture's current samples through
@@ -1220,6 +1227,7 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
 
   // ---- 6. write the samples that became final: 16x16 window at (-4,-3), chroma 8x8 at (-4,-1) --------
   const bool last_x = mbx == F.mb_w - 1, last_y = mby == F.mb_h - 1;
+#ifndef LH264_ABL_NOSTORE    // timing ablation only (no pictures)
   {
     const int rr = -3 + (lane >> 2), cc = -4 + 4 * (lane & 3);
     if ((rr >= 0 || mby > 0) && (cc >= 0 || mbx > 0))
@@ -1250,6 +1258,7 @@ __device__ __forceinline__ void process_mb (const FrameCtx& F, LDS WaveLds& L, c
         * (GLB uint32_t*) ((p ? F.dv : F.du) + (ptrdiff_t) (mby * 8 + 7) * F.sc + mbx * 8 + c2) = * (const LDS uint32_t*)&L.C[p][tC (7, c2)];
     }
   }
+#endif
   STAMP (7);
   // filtered bottom rows for the row below: tile rows 12..15 x cols [-4,11] (+ [12,15] at the last MB)
   if (!last_y) {

@@ -8,7 +8,9 @@ import torch  # noqa: F401  (HIP runtime first)
 import losslessh264_amd as lh
 data = open(os.path.join(ROOT, "tests", "golden", "streams", "BA_MW_D.264"), "rb").read()
 for n in [int(a) for a in sys.argv[1:]] or [64, 512]:
-    lh.compress_batch([data] * 4, 16)
+    t0 = time.perf_counter()
+    lh.compress_batch([data] * n, 16)          # first call of this size: the device and page-locked arenas grow (reported apart)
+    cold = time.perf_counter() - t0
     t0 = time.perf_counter()
     res = lh.compress_batch([data] * n, 16)
     dt = time.perf_counter() - t0
@@ -17,4 +19,5 @@ for n in [int(a) for a in sys.argv[1:]] or [64, 512]:
     outs = lh.restore_batch([(m, t) for m, t, _ in res], 16)
     dr = time.perf_counter() - t1
     assert all(o == data for o in outs)
-    print("streams=%d  compress_batch %.2f s (%.1f MB/s end to end)   restore_batch %.2f s (%.1f MB/s)" % (n, dt, n * len(data) / dt / 1e6, dr, n * len(data) / dr / 1e6), flush=True)
+    print("streams=%d  compress_batch %.3f s (%.1f MB/s end to end; first call of this size %.3f s)   restore_batch %.2f s (%.1f MB/s)" % (
+        n, dt, n * len(data) / dt / 1e6, cold, dr, n * len(data) / dr / 1e6), flush=True)
