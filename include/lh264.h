@@ -292,6 +292,9 @@ int   lh264_parser_feed (lh264_parser_t* p, const uint8_t* data, size_t len, int
  * decoder.cpp:658-860, au_parser.cpp:143,588, decode_slice.cpp:2974-2980), returned by lh264_parser_main_stream */
 int   lh264_parser_feed_file (lh264_parser_t* p, const uint8_t* data, size_t len);
 const uint8_t* lh264_parser_main_stream (const lh264_parser_t* p, size_t* len);
+/* the samples of the stream's I_PCM macroblocks (384 bytes each, decoding order): stream LH264_TAG_PCM of the container, see
+ * lh264_pip_restore */
+const uint8_t* lh264_parser_pcm_samples (const lh264_parser_t* p, size_t* len);
 int   lh264_parser_frame_count (const lh264_parser_t* p);
 int   lh264_parser_frame_info (const lh264_parser_t* p, int idx, lh264_frame_info_t* out);
 const lh264_mb_t*    lh264_parser_frame_mbs (const lh264_parser_t* p, int idx);
@@ -324,7 +327,11 @@ const char*          lh264_parser_error (const lh264_parser_t* p);
  * original Annex-B bytes (what `h264dec in.pip out.264` does in the reference: decode_slice.cpp:2476-2936, decoder.cpp:658-860).
  * tags[t] / tag_len[t] are indexed by tag id (billing.h:6-55), n_tags >= 70 to include the pad-bit tag 69; NULL = no such
  * stream.  *out_len receives the restored size; LH264_E_ARG when out_cap is too small (then *out_len = the size needed).
- * CAVLC streams only for now: a CABAC slice or an I_PCM macroblock gives LH264_E_UNSUPPORTED (lh264_restore_error: the text). */
+ * I_PCM macroblocks: the reference's representation does not carry their samples (its own restore aborts on them); ours adds one
+ * stream, tags[LH264_TAG_PCM] = the 384 samples of every I_PCM macroblock in decoding order, stored as they are.  With it CAVLC
+ * streams with I_PCM macroblocks restore; without it, and for I_PCM inside a CABAC slice, the call gives LH264_E_UNSUPPORTED
+ * (lh264_restore_error: the text) and the container falls back to VERBATIM. */
+#define LH264_TAG_PCM 70
 int lh264_pip_restore (const uint8_t* main_stream, size_t main_len, const uint8_t* const* tags, const size_t* tag_len, int n_tags,
                        uint8_t* out, size_t out_cap, size_t* out_len);
 const char* lh264_restore_error (void);       /* message of the calling thread's last failed lh264_pip_restore */

@@ -82,6 +82,7 @@ _SIGS.update({
     "lh264_pip_restore_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lh264_parser_feed_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "lh264_parser_main_stream": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "lh264_parser_pcm_samples": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "lh264_parser_frame_count": (C.c_int, [C.c_void_p]),
     "lh264_parser_frame_info": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lh264_parser_frame_mbs": (C.c_void_p, [C.c_void_p, C.c_int]),

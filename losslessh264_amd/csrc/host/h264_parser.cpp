@@ -904,7 +904,7 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
     if (mbt == 25) {                                    // I_PCM (7.3.5: pcm alignment + 384 samples)
       m.mb_type = LH264_MB_IPCM; s.type_class = 2;
       while (!br.byte_aligned()) br.u1();
-      for (int i = 0; i < 384; i++) coef[i] = (int16_t)br.u (8);
+      for (int i = 0; i < 384; i++) { coef[i] = (int16_t)br.u (8); self->pcm_.push_back ((uint8_t)coef[i]); }
       m.flags |= LH264_MBF_PCM_IN_COEFF;
       memset (m.nzc, 16, 24);
       m.qp_y = 0; m.qp_c[0] = m.qp_c[1] = 0;          // the reference stores QP 0 for I_PCM (decode_slice.cpp:3257-3258)
@@ -1286,7 +1286,7 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
     if (mbt == 25) {                                    // I_PCM: the samples follow byte aligned, then the engine restarts (9.3.1.2)
       m.mb_type = LH264_MB_IPCM; s.type_class = 2; s.pcm = 1; s.cbf = 0xffffffffu; s.cbp = 0x2f;
       size_t bp = (cb.pos + 7) & ~ (size_t)7;
-      for (int i = 0; i < 384; i++, bp += 8) coef[i] = (int16_t) (bp + 8 <= cb.nbits ? cb.p[bp >> 3] : 0);
+      for (int i = 0; i < 384; i++, bp += 8) { coef[i] = (int16_t) (bp + 8 <= cb.nbits ? cb.p[bp >> 3] : 0); self->pcm_.push_back ((uint8_t)coef[i]); }
       if (bp > cb.nbits) cb.err = true;
       cb.start (cb.p, cb.nbits / 8, bp);
       m.flags |= LH264_MBF_PCM_IN_COEFF;

@@ -231,6 +231,9 @@ class Parser {
   const std::vector<uint8_t>& last_rbsp() const;     // the unescaped payload of the NAL handled last
   static void unescape (const uint8_t* d, size_t n, std::vector<uint8_t>& out);
   const std::vector<uint8_t>& main_stream() const { return main_.buffer; }
+  // the samples of the stream's I_PCM macroblocks, 384 bytes each in decoding order: the reference's compressed representation does
+  // not carry them (its own restore fails on such streams); ours does, as one more stream of the container (LH264_TAG_PCM)
+  const std::vector<uint8_t>& pcm_samples() const { return pcm_; }
   // feed a whole Annex-B byte stream (or a piece that ends on a NAL boundary); completed pictures are appended to frames()
   int feed (const uint8_t* data, size_t len);
   int feed_nal (const uint8_t* nal, size_t len);      // one NAL unit without start code (with emulation prevention bytes)
@@ -265,6 +268,7 @@ class Parser {
   int n_unsupported_ = 0;
   bool keep_frames_ = true, want_coeffs_ = true, lazy_levels_ = false, sparse_levels_ = false; long pictures_done_ = 0;
   MainStreamWriter main_;
+  std::vector<uint8_t> pcm_;
   friend struct Impl;
 };
 

@@ -207,7 +207,8 @@ struct MbDec {                        // one decoded macroblock
 class Restorer {
  public:
   Restorer (const uint8_t* const* tags, const size_t* tag_len, int n_tags, std::string& err) : err_ (err) {
-    for (int t = 0; t < N_TAGS && t < n_tags; t++) if (tags[t]) { rd_[t].p = tags[t]; rd_[t].end = tags[t] + tag_len[t]; rd_[t].present = true; rd_[t].fill(); }
+    if (n_tags > LH264_TAG_PCM && tags[LH264_TAG_PCM]) { pcm_ = tags[LH264_TAG_PCM]; pcm_end_ = pcm_ + tag_len[LH264_TAG_PCM]; }
+    for (int t = 0; t < N_TAGS && t < n_tags; t++) if (t != LH264_TAG_PCM && tags[t]) { rd_[t].p = tags[t]; rd_[t].end = tags[t] + tag_len[t]; rd_[t].present = true; rd_[t].fill(); }
     build_vlc();
   }
   int run (const uint8_t* d, size_t n, std::vector<uint8_t>& out);
@@ -216,6 +217,7 @@ class Restorer {
   std::string& err_;
   bool failed_ = false;
   BoolReader rd_[N_TAGS];
+  const uint8_t* pcm_ = nullptr; const uint8_t* pcm_end_ = nullptr;     // samples of the I_PCM macroblocks still to be written
   DynProb test_prob_;                 // ArithmeticCodedInput::TEST_PROB: one adaptive probability shared by the raw bits of all tags
   PriorStore store_;
   Parser hdr_;
@@ -492,6 +494,15 @@ void Restorer::write_mb (const Parser::HeaderInfo& H, int k, const MbDec& m, int
   const bool intra = (type & LH264_MB_INTRA) != 0;
   const bool i16 = type == LH264_MB_I16x16;
   const int cbp = m.cbp_l | (m.cbp_c << 4);
+  if (type == LH264_MB_IPCM) {                          // 7.3.5: mb_type 25, alignment zeros, 256 + 2 x 64 samples; QP prediction is not touched
+    put_ue (25u + (is_p ? 5u : 0u));
+    while (w_.bits_in_byte() & 7) w_.emit_bit (0);
+    for (int i = 0; i < 384; i++) w_.emit_bits (pcm_[i], 8);
+    pcm_ += 384;
+    s.type_class = 2;
+    memset (s.nzc, 16, 24);
+    return;
+  }
   if (intra) {
     uint32_t mbt;
     if (i16) {
@@ -692,6 +703,20 @@ void Restorer::write_mb_cabac (const Parser::HeaderInfo& H, int k, const MbDec* 
   };
   auto t8_flag = [&] (int v) { ce_.encode (399 + (kA >= 0 && ws_[kA].t8) + (kB >= 0 && ws_[kB].t8), v); };
   bool t8 = false;
+  if (type == LH264_MB_IPCM) {
+    // mb_type 25: the prefix bin, then the terminating bin set, which flushes the engine (9.3.4.5) and leaves the stream byte aligned;
+    // the samples follow as they are and the engine starts afresh behind them, the context states kept (9.3.1.2)
+    if (is_p) ce_.encode (14, 1);
+    ce_.encode (is_p ? 17 : 3 + (kA >= 0 && ws_[kA].type_class != 1) + (kB >= 0 && ws_[kB].type_class != 1), 1);
+    ce_.terminate (1);
+    ce_.bytes.insert (ce_.bytes.end(), pcm_, pcm_ + 384);
+    pcm_ += 384;
+    ce_.low = 0; ce_.range = 510; ce_.outstanding = 0; ce_.first = true;
+    s.type_class = 2; s.cbf = 0xffffffffu; s.cbp = 0x2f;
+    memset (s.nzc, 16, 24);
+    last_dqp = 0;
+    return;
+  }
   if (intra) {
     int mbt = 0;
     if (i16) {
@@ -949,7 +974,8 @@ bool Restorer::decode_slice (const Parser::HeaderInfo& H) {
       if (nl) prior = type_code (nl->mb_type);
       if (np) prev = type_code (np->mb_type);
       const unsigned code = tree (TAG_MB_TYPE, LH264_TB_MBTYPE, (uint32_t) ((prior + prev) * 2 + (is_p ? 1 : 0)));
-      if (code > 7) { fail (code == 8 ? "I_PCM macroblocks are not supported by the restore direction" : "corrupt macroblock type"); return false; }
+      if (code > 8) { fail ("corrupt macroblock type"); return false; }
+      if (code == 8 && pcm_end_ - pcm_ < 384) { fail ("I_PCM macroblock without its samples (stream LH264_TAG_PCM)"); return false; }
       m.type = kCodeType[code];
     }
     const uint32_t type = m.type;

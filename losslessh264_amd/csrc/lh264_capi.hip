@@ -389,6 +389,11 @@ const uint8_t* lh264_parser_main_stream (const lh264_parser_t* p, size_t* len) {
   if (len) *len = p->p.main_stream().size();
   return p->p.main_stream().data();
 }
+const uint8_t* lh264_parser_pcm_samples (const lh264_parser_t* p, size_t* len) {
+  if (!p) return nullptr;
+  if (len) *len = p->p.pcm_samples().size();
+  return p->p.pcm_samples().data();
+}
 int lh264_parser_frame_count (const lh264_parser_t* p) { return p ? (int)const_cast<lh264_parser_t*> (p)->p.frames().size() : 0; }
 static const lh264host::FrameOut* pf (const lh264_parser_t* p, int idx) {
   if (!p) return nullptr;

@@ -260,8 +260,11 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
   std::vector<std::unique_ptr<lh264host::Parser>> parsers (n);
   std::thread device_thread;
   std::vector<int> running;                       // the group the device thread works on (its parsers are released when it is done)
+  double t_blocked = 0, t_serial = 0;
   auto launch = [&] (std::vector<int>& group) {
+    const double t_j = now_s();
     if (device_thread.joinable()) device_thread.join();
+    t_blocked += now_s() - t_j;
     running.swap (group); group.clear();
     if (running.empty()) return;
     device_thread = std::thread ([&, device] () {
@@ -285,10 +288,12 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
       if (data[i] || !len[i]) parsers[i]->feed_file (data[i], len[i]);
     });
     if (trace_on()) fprintf (stderr, "[lh264 compress] wave of %d streams parsed in %.3f s\n", w1 - w0, now_s() - t_p);
+    const double t_s = now_s();
     for (int i = w0; i < w1; i++) {
       lh264_compressed_t& r = *out[i];
       lh264host::Parser& P = *parsers[i];
       r.main_stream = P.main_stream();
+      if (!P.pcm_samples().empty()) { r.tag[LH264_TAG_PCM] = P.pcm_samples(); r.has_tag[LH264_TAG_PCM] = true; }
       r.pictures = (int)P.frames().size();
       size_t mbs = 0;
       bool symbols = true;
@@ -299,10 +304,11 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
       if (in_group && in_group + mbs > kBudget) { launch (group); in_group = 0; }
       group.push_back (i); in_group += mbs;
     }
+    t_serial += now_s() - t_s;
   }
   launch (group);
   if (device_thread.joinable()) device_thread.join();
-  if (trace_on()) fprintf (stderr, "[lh264 compress] %d streams: %.3f s\n", n, now_s() - t_call);
+  if (trace_on()) fprintf (stderr, "[lh264 compress] %d streams: %.3f s (between waves %.3f s, of which waiting for the device stage %.3f s)\n", n, now_s() - t_call, t_serial, t_blocked);
   return LH264_OK;
 }
 void lh264_compress_release (void) {

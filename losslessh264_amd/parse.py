@@ -10,10 +10,11 @@ class ParsedFrame:
     pass
 
 
-def parse_file(data, strict=False):
+def parse_file(data, strict=False, pcm=False):
     """A whole Annex-B file fed chunk by chunk as the reference's console application does.
-    -> (frames, error_text, main_stream): main_stream is the recompressor's default stream (the '.pip' file itself)."""
-    return parse_stream(data, strict, _file=True)
+    -> (frames, error_text, main_stream): main_stream is the recompressor's default stream (the '.pip' file itself).
+    pcm=True: a fourth element, the samples of the stream's I_PCM macroblocks (stream LH264_TAG_PCM of the container)."""
+    return parse_stream(data, strict, _file=True, _pcm=pcm)
 
 
 def parse_batch_time(datas, threads=0, keep=True):
@@ -41,7 +42,7 @@ def parse_batch_time(datas, threads=0, keep=True):
     return dt, pics
 
 
-def parse_stream(data, strict=False, _file=False):
+def parse_stream(data, strict=False, _file=False, _pcm=False):
     """-> (frames, error_text).  frames have the attributes ReconSession / CtxSession expect."""
     lib = L.lib()
     p = lib.lh264_parser_create()
@@ -82,7 +83,11 @@ def parse_stream(data, strict=False, _file=False):
         if _file:
             ln = C.c_size_t(0)
             ptr = lib.lh264_parser_main_stream(p, C.byref(ln))
-            return frames, err, (C.string_at(ptr, ln.value) if ln.value else b"")
+            main = C.string_at(ptr, ln.value) if ln.value else b""
+            if _pcm:
+                ptr = lib.lh264_parser_pcm_samples(p, C.byref(ln))
+                return frames, err, main, (C.string_at(ptr, ln.value) if ln.value else b"")
+            return frames, err, main
         return frames, err
     finally:
         lib.lh264_parser_destroy(p)

@@ -110,8 +110,8 @@ def test_command_line_compress_and_restore(tmp_path):
 
 
 def test_command_line_single_file_with_verbatim_fallback(tmp_path):
-    """`... in.264 out.lhp` / `... out.lhp back.264`: one container file; an I_PCM stream (which the round trip cannot carry, as in
-    the reference) is stored verbatim and still restores"""
+    """`... in.264 out.lhp` / `... out.lhp back.264`: one container file; a stream that does not get smaller (CABAC; I_PCM, whose
+    samples are carried as they are) is stored verbatim and still restores"""
     import subprocess
     import sys
     root = os.path.dirname(golden_io.GOLDEN_DIR.rstrip("/")).rsplit("/tests", 1)[0]
@@ -140,7 +140,9 @@ def test_compress_batch_c_api_equals_reference_cli():
         z = np.load(os.path.join(golden_io.GOLDEN_DIR, "cli_" + name + ".npz"))
         assert main == z["main"].tobytes(), name
         ref = {int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")}
-        assert tags == ref, (name, sorted(tags), sorted(ref))
+        pcm = tags.get(70)                            # LH264_TAG_PCM: our addition for I_PCM macroblocks, not one of the reference's files
+        assert {t: b for t, b in tags.items() if t != 70} == ref, (name, sorted(tags), sorted(ref))
+        assert (pcm is not None) == (name == "QCIF_2P_I_allIPCM.264") and (pcm is None or pcm == lh.parse_file(data, pcm=True)[3])
         assert lh.restore(main, tags) == data, name
 
 
@@ -183,7 +185,7 @@ def test_cpp_console_application(tmp_path):
     assert hashlib.sha1(open(yuv, "rb").read()).hexdigest() == sha[name]
     subprocess.check_call([exe, pip, back], timeout=300)
     assert open(back, "rb").read() == open(src, "rb").read()
-    # one container per stream, several streams in one call; the I_PCM stream falls back to verbatim
+    # one container per stream, several streams in one call; the I_PCM stream does not get smaller and is stored verbatim
     names = ["SVA_BA2_D.264", "tibby8x8cavlc.264", "QCIF_2P_I_allIPCM.264", "test_qcif_cabac.264"]
     outd = tmp_path / "batch"
     outd.mkdir()

@@ -5,7 +5,8 @@ oracle/Makefile): per stream the SHA-1 of every file it wrote in compress mode, 
 The exceptions are named, not counted away:
   * test_scalinglist_jm.264   the reference decodes nothing (weighted_bipred_idc), its "compressed" output is 184 bytes
   * Error_I_P.264, BA_MW_D_IDR_LOST.264   damaged streams: the reference conceals errors, the front end does not model that
-  * CVPCMNL1_SVA_C.264, QCIF_2P_I_allIPCM.264   I_PCM: neither the reference nor this code carries the samples through the round trip
+  * CVPCMNL1_SVA_C.264, QCIF_2P_I_allIPCM.264   I_PCM: the reference does not carry the samples through the round trip; this code adds
+    one stream for them (LH264_TAG_PCM) and restores both
 """
 import hashlib
 import json
@@ -24,7 +25,11 @@ MAIN_DIFFERS = {"test_scalinglist_jm.264"}
 TAGS_DIFFER = {"test_scalinglist_jm.264", "Error_I_P.264", "BA_MW_D_IDR_LOST.264"}
 # restore (compress (stream)) is not the stream for exactly these (BA_MW_D_IDR_LOST and test_scalinglist_jm do come back: what the
 # front end cannot model stays in the default stream)
-NO_RESTORE = {"Error_I_P.264", "CVPCMNL1_SVA_C.264", "QCIF_2P_I_allIPCM.264"}
+NO_RESTORE = {"Error_I_P.264"}
+# our one addition to the reference's file set: the samples of I_PCM macroblocks (include/lh264.h LH264_TAG_PCM), which the reference
+# does not store (its own restore aborts on such streams)
+TAG_PCM = 70
+HAVE_PCM = {"CVPCMNL1_SVA_C.264", "QCIF_2P_I_allIPCM.264"}
 
 
 def _sha(b):
@@ -62,15 +67,18 @@ def test_default_stream_equals_reference_on_all_but_the_named_streams():
 def test_compress_all_streams_on_the_gpu_and_restore():
     """the whole compress direction (front end -> HIP context-index + coder kernels) over all 44 streams in one batch: every file
     equals the reference's (SHA-1) except for the named streams; what equals the reference's files restores to the input (so the
-    reference's own files do), including 6 streams the reference itself aborts on"""
+    reference's own files do), including 9 streams the reference itself aborts on (two of them with I_PCM macroblocks, whose
+    samples travel in our additional stream LH264_TAG_PCM)"""
     import losslessh264_amd as lh
     datas = [_data(n) for n in STREAMS]
     res = lh.compress_batch(datas, 16)
     tags_differ, no_restore, restored_ref_fails = set(), set(), set()
     for name, data, (main, tags, err) in zip(STREAMS, datas, res):
         ref = SWEEP[name]["files"]
-        same = err is None and main is not None and set(str(t) for t in tags) == set(k for k in ref if k != "main") and \
-            _sha(main) == ref["main"][1] and all(_sha(tags[t]) == ref[str(t)][1] for t in tags)
+        assert err is not None or (TAG_PCM in tags) == (name in HAVE_PCM), name
+        ours = {t: b for t, b in (tags or {}).items() if t != TAG_PCM}
+        same = err is None and main is not None and set(str(t) for t in ours) == set(k for k in ref if k != "main") and \
+            _sha(main) == ref["main"][1] and all(_sha(ours[t]) == ref[str(t)][1] for t in ours)
         if not same:
             tags_differ.add(name)
         ok = False
@@ -87,4 +95,5 @@ def test_compress_all_streams_on_the_gpu_and_restore():
     assert no_restore == NO_RESTORE, sorted(no_restore ^ NO_RESTORE)
     # byte-identical files that the reference cannot restore but this code does
     assert restored_ref_fails == {"BASQP1_Sony_C.jsv", "CVFC1_Sony_C.jsv", "SVA_Base_B.264", "SVA_CL1_E.264", "SVA_FM1_E.264",
-                                  "test_cif_I_CABAC_slice.264", "test_cif_P_CABAC_slice.264"} - TAGS_DIFFER - NO_RESTORE, sorted(restored_ref_fails)
+                                  "test_cif_I_CABAC_slice.264", "test_cif_P_CABAC_slice.264",
+                                  "CVPCMNL1_SVA_C.264", "QCIF_2P_I_allIPCM.264"} - TAGS_DIFFER - NO_RESTORE, sorted(restored_ref_fails)
