@@ -62,12 +62,12 @@ def test_whole_stream_compress_equals_reference_cli_and_round_trips():
     """.264 -> (default stream from the host front end, tagged streams from the HIP coder) == the files the reference's console
     application writes; and those restore (csrc/host/pip_restore.cpp) to the input, bit for bit"""
     import losslessh264_amd as lh
-    datas, streams, mains = [], [], []
+    datas, streams, mains, pcms = [], [], [], []
     for name in CLI:
         data = open(os.path.join(golden_io.GOLDEN_DIR, "streams", name), "rb").read()
-        frames, err, main = lh.parse_file(data)
+        frames, err, main, pcm = lh.parse_file(data, pcm=True)
         assert err == ""
-        datas.append(data); streams.append(frames); mains.append(main)
+        datas.append(data); streams.append(frames); mains.append(main); pcms.append(pcm)
     ctx = lh.CtxSession(streams)
     ctx.run()
     coder = lh.CoderSession(ctx, hash_cap=1 << 18, out_cap=1 << 20)
@@ -81,6 +81,8 @@ def test_whole_stream_compress_equals_reference_cli_and_round_trips():
         assert sorted(got) == sorted(ref), (name, sorted(got), sorted(ref))
         for t in sorted(ref):
             assert got[t] == ref[t], "%s tag %d: %d bytes, reference %d" % (name, t, len(got[t]), len(ref[t]))
+        if pcms[c]:
+            got[70] = pcms[c]                         # LH264_TAG_PCM: the samples of I_PCM macroblocks, which the reference's files lack
         assert lh.restore(mains[c], got) == datas[c], name
 
 
