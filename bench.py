@@ -355,20 +355,24 @@ def main():
         outs = lh.restore_batch([(mains[0], tags)] * nb, ncpu)
         rt = time.perf_counter() - t1
         assert all(o == data for o in outs)
-        lh.compress_batch([data] * 4, ncpu)
-        t1 = time.perf_counter()
-        e2e = lh.compress_batch([data] * (4 * nb), ncpu)
-        et = time.perf_counter() - t1
-        assert all(e is None for _, _, e in e2e) and e2e[-1][1] == tags and e2e[-1][0] == mains[0]
-        del e2e
-        t1 = time.perf_counter()
-        e2e = lh.compress_batch([data] * (16 * nb), ncpu)          # four groups: parsing overlaps the device stage
-        et4 = time.perf_counter() - t1
-        assert all(e is None for _, _, e in e2e) and e2e[-1][1] == tags
-        del e2e
-        host_stages = {"threads": ncpu, "front_end_MB_per_s": nb * len(data) / pt / 1e6, "restore_MB_per_s": nb * len(data) / rt / 1e6,
-                       "compress_batch_end_to_end_%d_streams_MB_per_s" % (4 * nb): 4 * nb * len(data) / et / 1e6,
-                       "compress_batch_end_to_end_%d_streams_MB_per_s" % (16 * nb): 16 * nb * len(data) / et4 / 1e6}
+        # each size twice: the first call of a size also grows the device and page-locked arenas (reported apart), the second is the
+        # steady state of a service that keeps them
+        e2e_times = {}
+        for mult in (4, 16):                              # 512 streams: four groups already overlap parsing with the device stage
+            first = None
+            for attempt in range(2):
+                t1 = time.perf_counter()
+                e2e = lh.compress_batch([data] * (mult * nb), ncpu)
+                et = time.perf_counter() - t1
+                assert all(e is None for _, _, e in e2e) and e2e[-1][1] == tags and e2e[-1][0] == mains[0]
+                del e2e
+                if attempt == 0:
+                    first = et
+            e2e_times[mult * nb] = (et, first)
+        host_stages = {"threads": ncpu, "front_end_MB_per_s": nb * len(data) / pt / 1e6, "restore_MB_per_s": nb * len(data) / rt / 1e6}
+        for ns, (et, first) in e2e_times.items():
+            host_stages["compress_batch_end_to_end_%d_streams_MB_per_s" % ns] = ns * len(data) / et / 1e6
+            host_stages["compress_batch_end_to_end_%d_streams_first_call_MB_per_s" % ns] = ns * len(data) / first / 1e6
 
     if rank == 0:
         ms = dt / args.steps * 1e3

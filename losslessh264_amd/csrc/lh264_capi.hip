@@ -28,7 +28,13 @@ __global__ void coder_bases_kernel (uint32_t* chain_info, int n_chains, unsigned
 __global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* job_chain, int n_jobs,
                                    const uint32_t* seg_doff, const uint32_t* chain_info, uint64_t* D);
 __global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint64_t* D, uint16_t* Q, int n_chains);
-__global__ void coder_code_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, const uint16_t* Q, int n_chains, int groups);
+__global__ void coder_chunkmap_kernel (const uint32_t* chain_info, int n_pairs, uint32_t* pair_chunk0);
+__global__ void coder_range_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, int n_chains, int groups,
+                                    uint32_t* chunk_rec, uint32_t* pair_bits);
+__global__ void coder_accum_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, int n_pairs, const uint32_t* chunk_rec,
+                                    const uint32_t* pair_bits, uint32_t* acc);
+__global__ void coder_bytes_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_bits,
+                                    const uint32_t* acc, int n_pairs);
 __global__ void coder_status_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, int n_chains);
 size_t wave_lds_bytes();
 size_t wg_lds_bytes();
@@ -233,9 +239,20 @@ int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_fi
   HIPCHK (hipMemcpyAsync (W.totals_host, totals, 2 * sizeof (unsigned long long), hipMemcpyDeviceToHost, st));
   HIPCHK (hipStreamSynchronize (st));
   const unsigned long long n_words = W.totals_host[0], n_q = W.totals_host[1];
-  const size_t o_q = up256 ((size_t)n_words * 8 + 512);
-  if (int rc = grow (&W.big, &W.big_cap, o_q + (size_t)n_q * 2 + 256)) return rc;
-  uint64_t* D = (uint64_t*)W.big; uint16_t* Q = (uint16_t*) ((uint8_t*)W.big + o_q);
+  // the bool coder's tables: per (stream, tag slot) pair the first chunk (256 decisions) and the bits shifted out, per chunk its state at
+  // the first decision, per output byte position a 32-bit sum (one per list entry + 48 per pair bounds them)
+  const int n_pairs = n_chains * LH264_N_TAG_SLOTS;
+  if (n_pairs >= (1 << 24)) return fail (LH264_E_ARG, "too many streams in one call");
+  const size_t chunk_bound = (size_t)n_q / LH264_CODER_CODE_CHUNK + 2 * (size_t)n_pairs + 1;
+  const size_t n_acc = (size_t)n_q + 48 * (size_t)n_pairs + 64;
+  const size_t o_q = up256 ((size_t)n_words * 8 + 512), o_pc0 = o_q + up256 ((size_t)n_q * 2 + 256), o_pbits = o_pc0 + up256 ((size_t) (n_pairs + 1) * 4),
+               o_crec = o_pbits + up256 ((size_t)n_pairs * 4), o_acc = o_crec + up256 (chunk_bound * 8);
+  if (int rc = grow (&W.big, &W.big_cap, o_acc + n_acc * 4 + 256)) return rc;
+  uint8_t* bg = (uint8_t*)W.big;
+  uint64_t* D = (uint64_t*)bg; uint16_t* Q = (uint16_t*) (bg + o_q);
+  uint32_t* pair_chunk0 = (uint32_t*) (bg + o_pc0); uint32_t* pair_bits = (uint32_t*) (bg + o_pbits);
+  uint32_t* chunk_rec = (uint32_t*) (bg + o_crec); uint32_t* acc = (uint32_t*) (bg + o_acc);
+  HIPCHK (hipMemsetAsync (acc, 0, n_acc * 4, st));
   if (n_jobs > 0 && total_mbs > 0) {
     hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, job_chain, n_jobs, seg_doff, info, D);
     HIPCHK (hipGetLastError());
@@ -244,8 +261,14 @@ int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_fi
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_status_kernel, dim3 ((n_chains + 255) / 256), dim3 (256), 0, st, streams_dev, info, n_chains);
   HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_chunkmap_kernel, dim3 (1), dim3 (1024), 0, st, info, n_pairs, pair_chunk0);
+  HIPCHK (hipGetLastError());
   const int groups = (n_chains + 63) / 64;
-  hipLaunchKernelGGL (lh264::coder_code_kernel, dim3 ((unsigned)groups * 35), dim3 (64), 0, st, streams_dev, info, Q, n_chains, groups);
+  hipLaunchKernelGGL (lh264::coder_range_kernel, dim3 ((unsigned)groups * 35), dim3 (64), 0, st, info, Q, pair_chunk0, n_chains, groups, chunk_rec, pair_bits);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_accum_kernel, dim3 ((unsigned) ((chunk_bound + 255) / 256)), dim3 (256), 0, st, info, Q, pair_chunk0, n_pairs, chunk_rec, pair_bits, acc);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_bytes_kernel, dim3 ((unsigned) ((n_pairs + 63) / 64)), dim3 (64), 0, st, streams_dev, info, Q, pair_bits, acc, n_pairs);
   HIPCHK (hipGetLastError());
   W.last_words = n_words; W.last_q = n_q;
   // tag slots 35 .. LH264_N_TAG_SLOTS-1 do not exist: their lengths read 0

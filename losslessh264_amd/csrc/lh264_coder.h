@@ -26,6 +26,11 @@
 #endif
 #define LH264_CODER_RESOLVE_THREADS (64 * LH264_CODER_RESOLVE_WAVES)
 
+// the bool coder's output is summed up by chunks of this many decisions of a tag's list (a multiple of 8)
+#ifndef LH264_CODER_CODE_CHUNK
+#define LH264_CODER_CODE_CHUNK 256
+#endif
+
 // status bits reported in out_len_dev[LH264_N_TAG_SLOTS]
 #define LH264_CODER_ST_TABLE_FULL 1
 #define LH264_CODER_ST_OUT_FULL   4

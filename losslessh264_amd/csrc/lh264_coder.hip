@@ -6,20 +6,25 @@
 // that chain are really sequential: the state of ONE DynProb over the decisions made with it, and the state of ONE tag's bool coder
 // over the decisions sent to it.  Everything else is data parallel, so the work is cut into kernels along those two lines:
 //
-//   coder_count_kernel    one wave per macroblock, lane = symbol: binarise, count the decisions per tag           (parallel)
-//   coder_scan_kernel     per stream: where each macroblock's decisions start; size of every tag's list           (small)
-//   coder_emit_kernel     one wave per macroblock: binarise again, find-or-insert the prior's cell in the stream's hash
-//                         table (atomicCAS), write one 32-bit word per decision, in coding order                   (parallel)
-//   coder_resolve_kernel  one workgroup per stream, 64 decisions per wave step: a DynProb is two counters, so between two
-//                         rescales the probability a decision is coded with follows from PREFIX COUNTS of the earlier decisions
-//                         on the same DynProb.  Lanes holding the same DynProb find each other with ballots (no serial walk), the
-//                         only serial part is a short ticketed section per step: read the counters, write them back.  The
-//                         cells live in an LDS cache in front of the HBM table.  Output: (probability, bit) appended to the
-//                         list of the decision's tag.                                               (serial per stream, 64 wide)
-//   coder_code_kernel     one lane per (stream, tag): the libvpx bool coder over that tag's list                   (serial per tag)
+//   coder_count_kernel    per segment (<= 128 consecutive macroblocks of a picture), a thread per symbol: the number of decisions
+//                         per tag in closed form (sym_count), summed per segment                                   (parallel)
+//   coder_scan_kernel     per stream: where each segment's decisions start; size of every tag's list               (small)
+//   coder_bases_kernel    prefix over the streams; totals for the host                                              (small)
+//   coder_emit_kernel     per segment, four waves over its flat symbol list: binarise, write one 64-bit word per decision in
+//                         coding order (the key of the DynProb's cell, the place in it, bit, tag slot / raw bit)     (parallel)
+//   coder_resolve_kernel  one workgroup of 8 waves per stream, 64 decisions per wave step: a DynProb is two counters, so the
+//                         probability a decision is coded with follows from the counters before the step and PREFIX COUNTS of
+//                         the earlier decisions of the step on the same DynProb.  Lanes holding the same DynProb find each other
+//                         with ballots (no serial walk); the only serial part is a short ticketed section per step: read the
+//                         counters, write them back.  The counters live in a keyed LDS cache in front of a spill table in HBM.
+//                         Output: (probability of the bit that occurred, bit) appended to the list of the decision's tag.
+//                                                                                                  (serial per stream, 512 wide)
+//   coder_range_kernel    one lane per (stream, tag): the bool coder's range recurrence over that tag's list       (serial per tag)
+//   coder_accum_kernel, coder_bytes_kernel   the bool coder's `low`: addends summed per output byte position by chunks of the list,
+//                         then the carries and the bytes                                                            (parallel)
 //
-// A DynProb is packed into 32 bits (two 10-bit counts and the probability the next decision will use, which is NOT derivable
-// from the counts after a rescale), biased so that zero-filled memory is the initial state.  See DESIGN.md section 4.3.
+// Halving is lazy: the table holds the un-halved pair of counters and the reader halves when their sum has passed 512, so the
+// probability always follows from the pair; zero-filled memory is the initial state.  See DESIGN.md section 4.3.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/lh264.h"
@@ -42,8 +47,7 @@ __device__ __forceinline__ int wave_scan_add (int x) {
   return x;
 }
 
-// ---- DynProb, packed (compression_stream.h:87-115) ------------------------------------------------------------------------
-__device__ __forceinline__ int dp_prob (uint32_t s) { return (int) (((s >> 20) + 128u) & 255u); }
+// ---- DynProb (compression_stream.h:87-115): the probability from the two counters -------------------------------------------
 // floor (256 (c0+1) / (c0+c1+2)) < 256: numerator < 2^18, divisor <= 516: a float quotient is within one of the exact one
 __device__ __forceinline__ uint32_t dp_ratio (uint32_t c0, uint32_t c1) {
   const uint32_t num = 256u * (c0 + 1u), den = c0 + c1 + 2u;
@@ -51,13 +55,6 @@ __device__ __forceinline__ uint32_t dp_ratio (uint32_t c0, uint32_t c1) {
   if (prob * den > num) prob--;
   else if ((prob + 1u) * den <= num) prob++;
   return prob;
-}
-// the state after one more decision `bit` on counters (c0, c1)
-__device__ __forceinline__ uint32_t dp_after (uint32_t c0, uint32_t c1, int bit) {
-  if (bit) c1++; else c0++;
-  const uint32_t prob = dp_ratio (c0, c1);
-  if (c0 + c1 > 512u) { c0 = (c0 + 1u) >> 1; c1 = (c1 + 1u) >> 1; }
-  return c0 | (c1 << 10) | (((prob + 128u) & 255u) << 20);
 }
 
 __device__ __forceinline__ int tag_slot (int tag) { return tag == 69 ? 34 : tag; }
@@ -808,110 +805,277 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
   RS_STAMP_FLUSH
 }
 
-// ---- kernel 6: per (stream, tag) the libvpx bool coder (vpx_writer, bitwriter.h:35-105) with the carry resolved in registers -----
-struct Bc {
-  unsigned long long low64;
-  uint32_t range, pos, ffrun;
-  int count, pending, last;
-};
-__device__ __forceinline__ void bc_put (Bc& b, GLB uint8_t* out, uint32_t cap, int byte) {
-  if (b.pos < cap) out[b.pos] = (uint8_t)byte;
-  b.pos++;
-  b.last = byte;
-}
-__device__ __forceinline__ void bc_byte (Bc& b, GLB uint8_t* out, uint32_t cap, int byte, bool carry) {
-  if (carry) {                 // the pending byte takes the carry, the 0xff run behind it turns into zeros
-    bc_put (b, out, cap, b.pending + 1);
-    for (uint32_t i = 0; i < b.ffrun; i++) bc_put (b, out, cap, 0);
-    b.ffrun = 0; b.pending = byte;
-  } else if (b.pending < 0) b.pending = byte;
-  else if (byte == 0xff) b.ffrun++;
-  else {
-    bc_put (b, out, cap, b.pending);
-    for (uint32_t i = 0; i < b.ffrun; i++) bc_put (b, out, cap, 0xff);
-    b.ffrun = 0; b.pending = byte;
-  }
-}
-// vpx_write (bitwriter.h:35-105), cut in two so that the per-decision part is short (a single in-order wave pays every instruction):
-// bc_step adds and shifts in a 64-bit `low` and only counts the bits; bc_drain, called every few decisions, takes the bytes that
-// have become complete out of `low` (vpx_write does so at once, one byte at a time: the bytes are those of the same big number, and
-// a carry a later decision produces goes into the held bytes exactly as vpx_write's backward carry loop does).
-// Between drains at most four decisions: count < 28, low < 2^(24 + 28 + 9).
+// ---- kernels 6..9: the libvpx bool coder (vpx_writer, bitwriter.h:35-105; vpx_stop_encode bitwriter.cpp:17-37) ----------------
+// vpx_write keeps (low, range, count).  `range` depends only on the decisions so far - a 7-bit state that does not forget where it
+// started (two start values stay apart for hundreds of decisions: measured), so its recurrence is walked once, serially, per
+// (stream, tag); but that walk is all that is serial.  What vpx_write finally writes is one big number: every decision with bit 1
+// adds its `split` (8 bits) at the bit position given by the shifts before it, and carries run towards the first byte.  So:
+//   coder_chunkmap_kernel  chunks (CODE_CHUNK decisions) per (stream, tag) pair, running sum
+//   coder_range_kernel     one lane per pair: the range recurrence alone (no low, no bytes) - mad, two shifts, count-leading-zeros,
+//                          shift per decision -, noting range and bit position at the start of every chunk
+//   coder_accum_kernel     one lane per chunk: the recurrence again from the noted state; the addends go into 32-bit sums per output
+//                          byte position (a window in registers, atomic adds when it moves on)
+//   coder_bytes_kernel     one lane per pair: carries from the last byte to the first, the bytes, vpx_stop_encode's padding byte
+// The 32 "stop" decisions (bit 0, probability 128) are decisions n .. n+31 of a list.
 // A list entry is e = q << 1 | bit with q = the probability of the bit that occurred, in 1/256 (bit 0: the decision's probability p,
 // bit 1: 256 - p; written so by the resolve kernel).  With x = range - 1:  bit 0: what is left is split = (x p + 256) >> 8;  bit 1:
-// range - split = x - (x p >> 8) = (x (256 - p) + 255) >> 8.  One multiply-add for both, nothing on the serial chain but
-// mad -> shift -> count-leading-zeros -> shift.
-__device__ __forceinline__ void bc_step (Bc& b, uint32_t e) {
-  const uint32_t bit = e & 1u, q = e >> 1;
-  const uint32_t r = (__umul24 (b.range, q) + (256u - bit - q)) >> 8;                          // ((range - 1) q + 256 - bit) >> 8
-  b.low64 += (unsigned long long) ((b.range - r) & (0u - bit));                               // bit 1: low += split
-  const int shift = __clz ((int)r) - 24;                                                       // vpx_norm[r]: 1 <= r <= 255
-  b.range = r << shift;
-  b.low64 <<= shift;
-  b.count += shift;
+// range - split = x - (x p >> 8) = (x (256 - p) + 255) >> 8.  One multiply-add for both: rq = range q + (256 - bit - q) < 2^16,
+// r = rq >> 8, and the normalising shift (vpx_norm[r]) is the number of leading zeros of rq << 16.
+#define CODE_CHUNK ((uint32_t)LH264_CODER_CODE_CHUNK)
+#define CODE_STOP_ENTRY (128u << 1)
+struct CodeStep { uint32_t add, shift; };
+__device__ __forceinline__ CodeStep code_step (uint32_t& range, uint32_t e) {
+  const uint32_t q = (e >> 1) & 0x1ffu;
+  const uint32_t mask = 0u - (e & 1u);
+  const uint32_t k = 256u + mask - q;
+  uint32_t rq;                                             // one instruction on the serial chain (the compiler would fold k into it as two)
+  asm ("v_mad_u32_u24 %0, %1, %2, %3" : "=v" (rq) : "v" (range), "v" (q), "v" (k));
+  const uint32_t r = rq >> 8;
+  CodeStep s;
+  s.add = (range - r) & mask;
+  s.shift = (uint32_t)__builtin_clz (rq << 16);            // 1 <= r <= 255
+  range = r << s.shift;
+  return s;
 }
-__device__ __forceinline__ void bc_drain (Bc& b, GLB uint8_t* out, uint32_t cap) {
-  while (b.count >= 0) {
-    // 24 + count bits lie below the byte that is complete; the bit above it is a carry into what was put out before
-    const int below = 24 + b.count;
-    const uint32_t top = (uint32_t) (b.low64 >> below);
-    bc_byte (b, out, cap, (int) (top & 0xffu), (top & 0x100u) != 0);
-    b.low64 &= (1ull << below) - 1ull;
-    b.count -= 8;
+// entry i of a tag's list (16-bit entries behind `src`), the stop decisions behind the n real ones
+struct ListReader {
+  const GLB u32x4* src; uint32_t n; u32x4 cur; uint32_t have;       // `cur` holds entries have .. have + 7
+  __device__ __forceinline__ void init (const GLB uint16_t* list, uint32_t n_) { src = (const GLB u32x4*)list; n = n_; have = 0xffffffffu; }
+  __device__ __forceinline__ uint32_t at (uint32_t i) {
+    if (i >= n) return CODE_STOP_ENTRY;
+    if ((i & ~7u) != have) { have = i & ~7u; cur = src[i >> 3]; }
+    const uint32_t w = (i & 4u) ? ((i & 2u) ? cur.w : cur.z) : ((i & 2u) ? cur.y : cur.x);
+    return (w >> (16u * (i & 1u))) & 0xffffu;
   }
-}
-__device__ __forceinline__ void bc_finish (Bc& b, GLB uint8_t* out, uint32_t cap) {      // vpx_stop_encode + flush of the held bytes
-  for (int i = 0; i < 32; i++) { bc_step (b, 128u << 1); bc_drain (b, out, cap); }
-  if (b.pending >= 0) {
-    bc_put (b, out, cap, b.pending);
-    for (uint32_t i = 0; i < b.ffrun; i++) bc_put (b, out, cap, 0xff);
-  }
-  if ((b.last & 0xe0) == 0xc0) bc_put (b, out, cap, 0);
+};
+struct PairInfo { const GLB uint16_t* list; uint32_t n, total; bool used; unsigned long long acc0; };
+__device__ __forceinline__ PairInfo pair_info (const uint32_t* chain_info, const uint16_t* Q, uint32_t pair) {
+  const uint32_t chain = pair / LH264_N_TAG_SLOTS, slot = pair % LH264_N_TAG_SLOTS;
+  const uint32_t* I = chain_info + (size_t)chain * LH264_CODER_INFO_WORDS;
+  PairInfo P;
+  P.n = slot < 35u ? I[LH264_CODER_INFO_TAGCNT + slot] : 0u;
+  const unsigned long long tm = (unsigned long long)I[LH264_CODER_INFO_TOUCH] | (unsigned long long)I[LH264_CODER_INFO_TOUCH + 1] << 32;
+  P.used = slot < 35u && (P.n > 0u || ((tm >> slot) & 1ull));
+  P.total = P.used ? P.n + 32u : 0u;
+  const unsigned long long q0 = ((unsigned long long)I[LH264_CODER_INFO_QBASE] | (unsigned long long)I[LH264_CODER_INFO_QBASE + 1] << 32) + I[LH264_CODER_INFO_TAGBASE + (slot < 35u ? slot : 0u)];
+  P.list = glb<const uint16_t> (Q) + q0;
+  P.acc0 = q0 + 48ull * pair;                        // the pair's sums: fewer than n + 40 positions (a decision shifts out 7 bits at most)
+  return P;
 }
 
-// wave = one tag slot of 64 consecutive streams: the lanes of a wave run lists of about the same length
-__global__ void __launch_bounds__ (64)
-coder_code_kernel (const lh264_code_stream_t* __restrict__ streams, const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q,
-                   int n_chains, int groups) {
-  const int slot = blockIdx.x / groups, chain = (blockIdx.x % groups) * 64 + (int)threadIdx.x;
-  if (chain >= n_chains) return;
-  const uint32_t* I = chain_info + (size_t)chain * LH264_CODER_INFO_WORDS;
-  const lh264_code_stream_t* S = streams + chain;
-  const uint32_t n = I[LH264_CODER_INFO_TAGCNT + slot];
-  const unsigned long long tm = (unsigned long long)I[LH264_CODER_INFO_TOUCH] | (unsigned long long)I[LH264_CODER_INFO_TOUCH + 1] << 32;
-  const bool used = n > 0 || ((tm >> slot) & 1ull);
-  const GLB u32x4* src = (const GLB u32x4*) (glb<const uint16_t> (Q) + ((unsigned long long)I[LH264_CODER_INFO_QBASE] | (unsigned long long)I[LH264_CODER_INFO_QBASE + 1] << 32) +
-                                             I[LH264_CODER_INFO_TAGBASE + slot]);
-  const uint32_t cap = S->out_cap;
-  GLB uint8_t* o = glb<uint8_t> (S->out_dev) + (size_t)slot * cap;
-  Bc bc;
-  bc.pos = 0; bc.low64 = 0; bc.range = 255; bc.count = -24; bc.ffrun = 0; bc.pending = -1; bc.last = 0;
-  // the list is read four 16-byte pieces ahead of the coder (each piece is a memory round trip of its own for every lane)
-  const uint32_t pieces = (n + 7u) >> 3;
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  u32x4 p0 = pieces > 0 ? src[0] : zero4, p1 = pieces > 1 ? src[1] : zero4, p2 = pieces > 2 ? src[2] : zero4, p3 = pieces > 3 ? src[3] : zero4;
-  for (uint32_t c = 0; c < pieces; c++) {
-    const u32x4 v = p0;
-    p0 = p1; p1 = p2; p2 = p3; p3 = c + 4 < pieces ? src[c + 4] : zero4;
+// kernel 6: chunks per (stream, tag) pair and their running sum (one workgroup)
+__global__ void __launch_bounds__ (1024)
+coder_chunkmap_kernel (const uint32_t* __restrict__ chain_info, int n_pairs, uint32_t* __restrict__ pair_chunk0) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int p0 = 0; p0 < n_pairs; p0 += 1024) {
+    const int p = p0 + tid;
+    uint32_t v = 0;
+    if (p < n_pairs) {
+      const uint32_t chain = (uint32_t)p / LH264_N_TAG_SLOTS, slot = (uint32_t)p % LH264_N_TAG_SLOTS;
+      const uint32_t* I = chain_info + (size_t)chain * LH264_CODER_INFO_WORDS;
+      const uint32_t n = slot < 35u ? I[LH264_CODER_INFO_TAGCNT + slot] : 0u;
+      const unsigned long long tm = (unsigned long long)I[LH264_CODER_INFO_TOUCH] | (unsigned long long)I[LH264_CODER_INFO_TOUCH + 1] << 32;
+      if (slot < 35u && (n > 0u || ((tm >> slot) & 1ull))) v = (n + 32u + CODE_CHUNK - 1u) / CODE_CHUNK;
+    }
+    const uint32_t incl = (uint32_t)wave_scan_add ((int)v);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = carry;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    if (p < n_pairs) pair_chunk0[p] = before + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) pair_chunk0[n_pairs] = carry;
+}
+
+// kernel 7: per pair, the range recurrence over the whole list; per chunk {range | pair << 8, bits shifted out} at its first decision.
+// A wave = one tag slot of 64 consecutive streams: lists of about the same length in its lanes.  (Two lists per lane, their steps
+// interleaved in one instruction stream, were slower - 4.2 vs 3.1 ms: a lone wave is bound by the number of instructions it issues,
+// not by the latency of the recurrence.)
+// Loads the compiler does not know about: a loop that reads ahead through ordinary loads gets "s_waitcnt vmcnt(0)" at its head
+// (the loop-carried loads are tracked conservatively), i.e. one memory round trip per iteration.  Here the load and the wait are
+// written out: `code_ld16` starts a 16-byte load into v (tied: the register is not renamed, nothing copies it while the data is
+// under way), `code_wait<N>` waits until at most N younger vector-memory operations are outstanding and is v's first reader.
+__device__ __forceinline__ void code_ld16 (u32x4& v, const GLB u32x4* p) { asm volatile ("global_load_dwordx4 %0, %1, off" : "+v" (v) : "v" (p) : "memory"); }
+template <int N> __device__ __forceinline__ void code_wait (u32x4& v) { asm volatile ("s_waitcnt vmcnt(%1)" : "+v" (v) : "n" (N) : "memory"); }
+
+struct RangeWalk {
+  GLB uint32_t* rec; uint32_t range, pos, g0, pair;
+  __device__ __forceinline__ void note (uint32_t i) { const size_t g = g0 + i / CODE_CHUNK; rec[2 * g] = range | pair << 8; rec[2 * g + 1] = pos; }
+  // one whole piece (8 decisions): no test per decision; a chunk starts on a piece
+  __device__ __forceinline__ void piece (const u32x4 v, uint32_t c) {
+    if ((c & (CODE_CHUNK / 8 - 1u)) == 0u) note (c * 8u);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    const uint32_t q = c << 3;
-    if (q + 8u <= n) {                    // a whole piece: no per-decision test, the bytes taken out twice
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        bc_step (bc, (w[i >> 1] >> (16 * (i & 1))) & 0x3ffu);
-        if ((i & 3) == 3) bc_drain (bc, o, cap);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        if (q + (uint32_t)i < n) { bc_step (bc, (w[i >> 1] >> (16 * (i & 1))) & 0x3ffu); bc_drain (bc, o, cap); }
-      }
+    for (int q = 0; q < 8; q++) pos += code_step (range, w[q >> 1] >> (16 * (q & 1))).shift;
+  }
+};
+#define CODE_AHEAD 8u        // 16-byte pieces of the list under way per lane
+__global__ void __launch_bounds__ (64)
+coder_range_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0, int n_chains,
+                    int groups, uint32_t* __restrict__ chunk_rec, uint32_t* __restrict__ pair_bits) {
+  const uint32_t slot = blockIdx.x / (uint32_t)groups, chain = (blockIdx.x % (uint32_t)groups) * 64u + threadIdx.x;
+  if (chain >= (uint32_t)n_chains) return;
+  RangeWalk A;
+  A.pair = chain * LH264_N_TAG_SLOTS + slot; A.range = 255u; A.pos = 0; A.rec = glb<uint32_t> (chunk_rec);
+  A.g0 = pair_chunk0[A.pair];
+  if (pair_chunk0[A.pair + 1] != A.g0) {
+    const PairInfo P = pair_info (chain_info, Q, A.pair);
+    const uint32_t n = P.n, pieces = (n + 7u) >> 3, whole = n >> 3, last = pieces ? pieces - 1u : 0u;
+    const GLB u32x4* src = (const GLB u32x4*)P.list;
+    // eight separate registers quadruples (an array would be one aggregate that the compiler copies around while loads are under way)
+    u32x4 b0 = {0u, 0u, 0u, 0u}, b1 = b0, b2 = b0, b3 = b0, b4 = b0, b5 = b0, b6 = b0, b7 = b0;
+#define CODE_FIRST(B, J) if (pieces) code_ld16 (B, src + min ((uint32_t) (J), last));
+    CODE_FIRST (b0, 0) CODE_FIRST (b1, 1) CODE_FIRST (b2, 2) CODE_FIRST (b3, 3) CODE_FIRST (b4, 4) CODE_FIRST (b5, 5) CODE_FIRST (b6, 6) CODE_FIRST (b7, 7)
+#undef CODE_FIRST
+    uint32_t c = 0;
+    // CODE_AHEAD loads are under way all the time (behind the end of the list the last piece is read again), so the oldest one has
+    // arrived when at most CODE_AHEAD - 1 are outstanding
+#define CODE_TURN(B, J) code_wait<CODE_AHEAD - 1> (B); A.piece (B, c + (J)); code_ld16 (B, src + min (c + (J) + CODE_AHEAD, last));
+    for (; c + CODE_AHEAD <= whole; c += CODE_AHEAD) {
+      CODE_TURN (b0, 0u) CODE_TURN (b1, 1u) CODE_TURN (b2, 2u) CODE_TURN (b3, 3u) CODE_TURN (b4, 4u) CODE_TURN (b5, 5u) CODE_TURN (b6, 6u) CODE_TURN (b7, 7u)
+    }
+#undef CODE_TURN
+    code_wait<0> (b0); code_wait<0> (b1); code_wait<0> (b2); code_wait<0> (b3); code_wait<0> (b4); code_wait<0> (b5); code_wait<0> (b6); code_wait<0> (b7);
+    // fewer than CODE_AHEAD whole pieces are left: register j holds piece min (c + j, last); then the last, partial piece
+    const uint32_t left = whole - c;
+    u32x4 pv = b0;
+#define CODE_LAST(B, J) if ((J) < left) A.piece (B, c + (J)); if (left == (J)) pv = B;
+    CODE_LAST (b0, 0u) CODE_LAST (b1, 1u) CODE_LAST (b2, 2u) CODE_LAST (b3, 3u) CODE_LAST (b4, 4u) CODE_LAST (b5, 5u) CODE_LAST (b6, 6u) CODE_LAST (b7, 7u)
+#undef CODE_LAST
+    const uint32_t w[4] = {pv.x, pv.y, pv.z, pv.w};
+    for (uint32_t i = whole * 8u; i < P.total; i++) {
+      if ((i & (CODE_CHUNK - 1u)) == 0u) A.note (i);
+      const uint32_t j = i & 7u;
+      const uint32_t wj = (j & 4u) ? ((j & 2u) ? w[3] : w[2]) : ((j & 2u) ? w[1] : w[0]);
+      A.pos += code_step (A.range, i < n ? wj >> (16u * (j & 1u)) : CODE_STOP_ENTRY).shift;
     }
   }
+  pair_bits[A.pair] = A.pos;                            // all the bits the list shifts out
+}
+
+// kernel 8: the addends of every chunk into the sums of the output byte positions.  A position takes addends from the decisions that
+// start in its byte or in the byte before; the positions strictly inside a chunk's span of bits belong to that chunk alone and are
+// stored, the two at either end are shared with the neighbouring chunks and added atomically (the sums start out as zero).
+__global__ void __launch_bounds__ (256)
+coder_accum_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0, int n_pairs,
+                    const uint32_t* __restrict__ chunk_rec, const uint32_t* __restrict__ pair_bits, uint32_t* __restrict__ acc) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= pair_chunk0[n_pairs]) return;
+  uint32_t range = chunk_rec[2 * (size_t)g], t = chunk_rec[2 * (size_t)g + 1];
+  const uint32_t pair = range >> 8;
+  range &= 0xffu;
+  const PairInfo P = pair_info (chain_info, Q, pair);
+  const uint32_t c = g - pair_chunk0[pair], i0 = c * CODE_CHUNK, i1 = min (i0 + CODE_CHUNK, P.total);
+  const uint32_t t_end = g + 1u < pair_chunk0[pair + 1] ? chunk_rec[2 * (size_t)g + 3] : pair_bits[pair];     // where the next chunk starts
+  const uint32_t own_lo = (t >> 3) + 2u, own_hi = t_end >> 3;            // positions own_lo .. own_hi - 1 are this chunk's alone
+  GLB uint32_t* A = glb<uint32_t> (acc) + P.acc0;
+  auto put = [&] (uint32_t kpos, uint32_t v) {
+    if (v == 0u) return;
+#ifndef LH264_ABL_CODE_NOATOMIC     // timing ablation only (wrong output)
+    if (kpos >= own_lo && kpos < own_hi) A[kpos] = v;
+    else atomicAdd ((uint32_t*) (uintptr_t) (A + kpos), v);
+#endif
+  };
+  // window: the addends at byte position kb (bits 8 and up of w) and kb + 1 (bits 0..7); an addend starts t bits behind the list's first bit
+  uint32_t kb = t >> 3, w = 0;
+  auto one = [&] (uint32_t e) {
+    const CodeStep s = code_step (range, e);
+    if (s.add) {
+      const uint32_t k = t >> 3;
+      if (k != kb) {
+        put (kb, w >> 8);
+        if (k == kb + 1u) w = (w & 0xffu) << 8;
+        else { put (kb + 1u, w & 0xffu); w = 0; }
+        kb = k;
+      }
+      w += s.add << (8u - (t & 7u));
+    }
+    t += s.shift;
+  };
+  // whole pieces of the chunk, read four ahead (a chunk starts on a piece); then what is left of the list and the stop decisions
+  const GLB u32x4* src = (const GLB u32x4*)P.list;
+  const uint32_t c0 = i0 >> 3, c1 = min (i1, P.n) >> 3;         // pieces c0 .. c1-1 lie inside the chunk and inside the list
+  // (ordinary loads here: the atomics and stores between them are vector-memory operations too, a counted wait would wait for
+  // nearly everything; with thousands of chunks per SIMD the latency is covered by other waves)
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 p0 = c0 < c1 ? src[c0] : zero4, p1 = c0 + 1 < c1 ? src[c0 + 1] : zero4, p2 = c0 + 2 < c1 ? src[c0 + 2] : zero4, p3 = c0 + 3 < c1 ? src[c0 + 3] : zero4;
+  for (uint32_t cc = c0; cc < c1; cc++) {
+    const u32x4 v = p0;
+    p0 = p1; p1 = p2; p2 = p3; p3 = cc + 4 < c1 ? src[cc + 4] : zero4;
+    const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 8; q++) one (wd[q >> 1] >> (16 * (q & 1)));
+  }
+  ListReader L; L.init (P.list, P.n);
+  for (uint32_t i = max (i0, c1 * 8u); i < i1; i++) one (L.at (i));
+  put (kb, w >> 8);
+  put (kb + 1u, w & 0xffu);
+}
+
+// kernel 9: carries, bytes, lengths.  vpx_write puts a byte out whenever 8 more bits have been shifted out beyond the first 24:
+// bytes = (bits - 24) / 8 + 1; byte k is byte position k of the sum.  vpx_stop_encode appends a zero byte behind a last byte 110xxxxx.
+__global__ void __launch_bounds__ (64)
+coder_bytes_kernel (const lh264_code_stream_t* __restrict__ streams, const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q,
+                    const uint32_t* __restrict__ pair_bits, const uint32_t* __restrict__ acc, int n_pairs) {
+  const uint32_t pair = blockIdx.x * 64u + threadIdx.x;
+  if (pair >= (uint32_t)n_pairs) return;
+  const uint32_t chain = pair / LH264_N_TAG_SLOTS, slot = pair % LH264_N_TAG_SLOTS;
+  if (slot >= 35u) return;                             // tag slots that do not exist (their lengths are cleared by the status kernel)
+  const lh264_code_stream_t* S = streams + chain;
   GLB uint32_t* lens = glb<uint32_t> (S->out_len_dev);
-  if (used) bc_finish (bc, o, cap);
-  lens[slot] = used ? bc.pos : 0u;
-  if (used && bc.pos > cap) atomicOr ((uint32_t*) (uintptr_t) (lens + LH264_N_TAG_SLOTS), (uint32_t)LH264_CODER_ST_OUT_FULL);
+  const PairInfo P = pair_info (chain_info, Q, pair);
+  if (!P.used) { lens[slot] = 0; return; }
+  const uint32_t bits = pair_bits[pair], cap = S->out_cap;
+  uint32_t nbytes = bits >= 24u ? ((bits - 24u) >> 3) + 1u : 0u;
+  const GLB uint32_t* A = glb<const uint32_t> (acc) + P.acc0;
+  GLB uint8_t* o = glb<uint8_t> (S->out_dev) + (size_t)slot * cap;
+  // sums behind the last byte that is put out carry into it as well
+  uint32_t carry = 0;
+  const uint32_t last = (bits >> 3) + 2u;                      // no addend lies behind this position
+  for (uint32_t k = last; k + 1u > nbytes; k--) carry = (A[k] + carry) >> 8;           // positions last .. nbytes
+  uint32_t final_byte = 0;
+  uint32_t k = nbytes;
+  for (; (k & 3u) != 0u; ) {                          // down to a multiple of four positions, then four sums (and four bytes) at a time
+    k--;
+    const uint32_t v = A[k] + carry;
+    carry = v >> 8;
+    if (k < cap) o[k] = (uint8_t)v;
+    if (k == nbytes - 1u) final_byte = v & 0xffu;
+  }
+  const bool wide = (((uintptr_t)o) & 3u) == 0u;
+  // four positions (and four bytes) per step; the sums are read four steps ahead of the carry chain (code_ld16 / code_wait: the loop
+  // would otherwise wait for every load it has just issued)
+  auto four = [&] (const u32x4 q) {
+    k -= 4u;
+    const uint32_t v3 = q.w + carry, v2 = q.z + (v3 >> 8), v1 = q.y + (v2 >> 8), v0 = q.x + (v1 >> 8);
+    carry = v0 >> 8;
+    if (k + 3u == nbytes - 1u) final_byte = v3 & 0xffu;
+    const uint32_t word = (v0 & 0xffu) | (v1 & 0xffu) << 8 | (v2 & 0xffu) << 16 | (v3 & 0xffu) << 24;
+    if (wide && k + 3u < cap) * (GLB uint32_t*) (o + k) = word;
+    else { if (k < cap) o[k] = (uint8_t)v0; if (k + 1u < cap) o[k + 1] = (uint8_t)v1; if (k + 2u < cap) o[k + 2] = (uint8_t)v2; if (k + 3u < cap) o[k + 3] = (uint8_t)v3; }
+  };
+  u32x4 f0 = {0u, 0u, 0u, 0u}, f1 = f0, f2 = f0, f3 = f0;
+  code_ld16 (f0, (const GLB u32x4*) (A + (k >= 4u ? k - 4u : 0u)));
+  code_ld16 (f1, (const GLB u32x4*) (A + (k >= 8u ? k - 8u : 0u)));
+  code_ld16 (f2, (const GLB u32x4*) (A + (k >= 12u ? k - 12u : 0u)));
+  code_ld16 (f3, (const GLB u32x4*) (A + (k >= 16u ? k - 16u : 0u)));
+#define CODE_TURN(F) code_wait<3> (F); four (F); code_ld16 (F, (const GLB u32x4*) (A + (k >= 16u ? k - 16u : 0u)));
+  while (k >= 16u) { CODE_TURN (f0) CODE_TURN (f1) CODE_TURN (f2) CODE_TURN (f3) }
+#undef CODE_TURN
+  code_wait<0> (f0); code_wait<0> (f1); code_wait<0> (f2); code_wait<0> (f3);
+  if (k >= 4u) four (f0);
+  if (k >= 4u) four (f1);
+  if (k >= 4u) four (f2);
+  if (nbytes > 0u && (final_byte & 0xe0u) == 0xc0u) { if (nbytes < cap) o[nbytes] = 0; nbytes++; }
+  lens[slot] = nbytes;
+  if (nbytes > cap) atomicOr ((uint32_t*) (uintptr_t) (lens + LH264_N_TAG_SLOTS), (uint32_t)LH264_CODER_ST_OUT_FULL);
 }
 
 // the status word of every stream, before the coding kernel adds its own bit

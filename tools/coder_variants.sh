@@ -8,4 +8,4 @@ for v in $R/build/variants/lib*.so; do
   n=$(basename $v .so)
   LH264_SO=$v timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$n -- python3 $R/tools/coder_kernels.py ${2:-512} 2>&1 | grep "so="
 done
-python3 $R/tools/summarize_stats.py "$OUT/*/*/*kernel_stats.csv" | grep "==\|coder_resolve\|coder_code\|coder_emit\|coder_count"
+python3 $R/tools/summarize_stats.py "$OUT/*/*/*kernel_stats.csv" | grep "==\|coder_"
