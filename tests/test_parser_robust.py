@@ -14,8 +14,12 @@ def test_parser_survives_damaged_streams(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "parser_stress.cpp"),
                            os.path.join(host, "h264_parser.cpp"), os.path.join(host, "pip_symbols.cpp"), "-o", exe])
+    # every stream of up to 64 KB (27 of the 44: CAVLC and CABAC, lost packets, I_PCM, scaling lists, FMO/ASO headers) and three larger ones
+    # with the 8x8 transform, CABAC P pictures and multiple reference pictures; 67 damaged variants of each.  (All 44 streams take eight
+    # minutes under the sanitizers; the whole CPU suite is meant to run in a few.)
     streams = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "streams", "*")))
-    assert len(streams) >= 8
+    streams = [s for s in streams if os.path.getsize(s) <= 65536 or os.path.basename(s) in ("tibbycabac.264", "tibby8x8cavlc.264", "MR1_BT_A.h264")]
+    assert len(streams) >= 25
     r = subprocess.run([exe] + streams, capture_output=True, timeout=900,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0, (r.stdout.decode()[-2000:], r.stderr.decode()[-6000:])
