@@ -328,16 +328,16 @@ const char*          lh264_parser_error (const lh264_parser_t* p);
  * tags[t] / tag_len[t] are indexed by tag id (billing.h:6-55), n_tags >= 70 to include the pad-bit tag 69; NULL = no such
  * stream.  *out_len receives the restored size; LH264_E_ARG when out_cap is too small (then *out_len = the size needed).
  * I_PCM macroblocks: the reference's representation does not carry their samples (its own restore aborts on them); ours adds one
- * stream, tags[LH264_TAG_PCM] = the 384 samples of every I_PCM macroblock in decoding order, stored as they are.  With it CAVLC
- * streams with I_PCM macroblocks restore; without it, and for I_PCM inside a CABAC slice, the call gives LH264_E_UNSUPPORTED
- * (lh264_restore_error: the text) and the container falls back to VERBATIM. */
+ * stream, tags[LH264_TAG_PCM] = the 384 samples of every I_PCM macroblock in decoding order, stored as they are.  With it streams
+ * with I_PCM macroblocks restore (CAVLC: 7.3.5; CABAC: the engine is flushed before the samples and restarted behind them,
+ * 9.3.1.2); without it the call gives LH264_E_UNSUPPORTED (lh264_restore_error: the text). */
 #define LH264_TAG_PCM 70
 int lh264_pip_restore (const uint8_t* main_stream, size_t main_len, const uint8_t* const* tags, const size_t* tag_len, int n_tags,
                        uint8_t* out, size_t out_cap, size_t* out_len);
 const char* lh264_restore_error (void);       /* message of the calling thread's last failed lh264_pip_restore */
 
 /* ---- single-file container: the default stream and the tagged streams in one file, or - flag VERBATIM - the
- * input itself for streams the round trip cannot carry (I_PCM, damaged streams, syntax the front end does not parse), so that
+ * input itself for streams the round trip cannot carry (damaged streams, syntax the front end does not parse) or does not shrink, so that
  * every input restores.  Layout: "LHPIP1\0\0", u32 flags, u32 n, n x {u32 stream id (0x7fffffff = default stream, else the
  * tag id), u32 length}, the payloads in that order; little endian.  The reference has no counterpart (it writes one file per
  * stream, h264dec.cpp:79-104, and aborts on what it cannot restore). */
