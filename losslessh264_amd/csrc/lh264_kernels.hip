@@ -1417,18 +1417,23 @@ recon_chain_kernel (const lh264_frame_job_t* __restrict__ jobs, const int32_t* _
     const int jprev = row > 0 ? (g - 1 - wprev) / NW : 0;
     Pref pf = prefetch_mb (F, row * F.mb_w, row > 0, lane);
     unsigned long long below = 0;            // bit i: macroblock 64*(x/64)+i of the row below is intra
+    unsigned long long ahead = 0;            // bit i: macroblock 64*(x/64)+i+1 of this row is intra
     for (int x = 0; x < F.mb_w; x++) {
+      if ((x & 63) == 0) {                   // (before the prefetch: these two loads are waited for at once)
+        int t = 0, u = 0;
+        if (row + 1 < F.mb_h && x + lane < F.mb_w) t = * (const GLB uint16_t*) (F.mbs + (size_t) (row + 1) * F.mb_w + x + lane);
+        if (x + 1 + lane < F.mb_w) u = * (const GLB uint16_t*) (F.mbs + (size_t)row * F.mb_w + x + 1 + lane);
+        below = __ballot ((t & LH264_MB_INTRA) != 0);
+        ahead = __ballot ((u & LH264_MB_INTRA) != 0);
+      }
       Pref nx = pf;
       if (x + 1 < F.mb_w) nx = prefetch_mb (F, row * F.mb_w + x + 1, row > 0, lane);
-      if ((x & 63) == 0) {
-        int t = 0;
-        if (row + 1 < F.mb_h && x + lane < F.mb_w) t = * (const GLB uint16_t*) (F.mbs + (size_t) (row + 1) * F.mb_w + x + lane);
-        below = __ballot ((t & LH264_MB_INTRA) != 0);
-      }
       // does an intra macroblock read this one's unfiltered bottom row (below-left, below, below-right) / right column?
+      // (the type of the next macroblock comes from the row's mask, not from the record just requested: looking at that one here
+      // would wait for the prefetch the moment it is issued)
       const int xi = x & 63;
       const bool pub_line = row + 1 < F.mb_h && (xi == 0 || xi >= 62 || ((below >> (xi - 1)) & 7) != 0);
-      const bool pub_left = x + 1 < F.mb_w && (uni ((int)nx.rec) & LH264_MB_INTRA) != 0;
+      const bool pub_left = x + 1 < F.mb_w && ((ahead >> xi) & 1) != 0;
       const int need = (jprev << 12) | min (x + 2, F.mb_w);
       STAMP (8);
       // The lane index goes in opaque: otherwise every lane-dependent address and mask of the macroblock's steps is hoisted out of
