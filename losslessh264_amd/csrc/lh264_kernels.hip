@@ -975,15 +975,20 @@ __device__ LH264_PHASE void deblock_phase (LDS WaveLds& L, const LDS WgLds& G, R
                                             bool left_av, bool top_av, int lane) {
   const int mtype = uni (m.mb_type());
   const bool mintra = (mtype == LH264_MB_I4x4 || mtype == LH264_MB_I8x8 || mtype == LH264_MB_I16x16 || mtype == LH264_MB_IPCM);
+  int my_bs = 0;
   if (lane < 32) {
     const int dir = lane >> 4, e = (lane >> 2) & 3, seg = lane & 3;
     // with the 8x8 transform the luma edges 1 and 3 do not exist (deblocking.cpp:836-849; chroma never uses them)
     const bool t8 = (m.flags() & LH264_MBF_T8x8) != 0;
-    L.bs[lane] = (t8 && (e & 1)) ? 0 : (uint8_t)compute_bs (m, dir == 0 ? lm : tm, dir == 0 ? left_av : top_av, dir, e, seg, mintra);
+    my_bs = (t8 && (e & 1)) ? 0 : compute_bs (m, dir == 0 ? lm : tm, dir == 0 ? left_av : top_av, dir, e, seg, mintra);
+    L.bs[lane] = (uint8_t)my_bs;
   }
+  // which of the 2 x 4 edges have any strength at all: one scalar mask (bit 16 dir + 4 edge + segment), so that an edge nobody
+  // filters costs a scalar branch and nothing else
+  const uint32_t live = (uint32_t)__ballot (my_bs != 0);
   wsync();
   const v4u bs0 = * (const LDS v4u*)&L.bs[0], bs1 = * (const LDS v4u*)&L.bs[16];     // [edge] = 4 segment bytes
-  const bool any0 = uni ((int) (bs0.x | bs0.y | bs0.z | bs0.w)) != 0, any1 = uni ((int) (bs1.x | bs1.y | bs1.z | bs1.w)) != 0;
+  const bool any0 = (live & 0xffffu) != 0, any1 = (live >> 16) != 0;
   if ((!any0 && !any1) || lane >= 32) return;
 #ifdef LH264_ABL_BSONLY      // timing ablation only (wrong pictures): boundary strengths, no filtering
   return;
@@ -1012,7 +1017,16 @@ __device__ LH264_PHASE void deblock_phase (LDS WaveLds& L, const LDS WgLds& G, R
     if (chroma && cpl == 0 && (tab[TAB_ALPHA + iar] | tab[TAB_BETA + tab_idx (qr + bo)])) tcc_h = * (const LDS uint32_t*)&tab[TAB_TC0 + 4 * iar];
   }
   int v[20];
-  if (any0) {
+  if (any0 && (live & 0xfff0u) == 0) {
+    // ---- vertical edges, only the macroblock edge is live: samples -4..3 of the row ------------------------------------------------
+    LDS uint32_t* rowp = (LDS uint32_t*) (chroma ? &L.C[cpl][tC (li, -4)] : &L.T[tY (li, -4)]);
+    const uint32_t w0 = rowp[0], w1 = rowp[1];
+    int p3 = BYTE (w0, 0), p2 = BYTE (w0, 1), p1 = BYTE (w0, 2), p0 = BYTE (w0, 3), q0 = BYTE (w1, 0), q1 = BYTE (w1, 1), q2 = BYTE (w1, 2), q3 = BYTE (w1, 3);
+    const int bs = (int) ((bs0.x >> sh8) & 0xff);
+    filter_edge (p3, p2, p1, p0, q0, q1, q2, q3, (all_ | bel) ? bs : 0, all_, bel, (int) ((tcl >> (8 * (bs & 3))) & 0xff), chroma);
+    rowp[0] = (uint32_t)p3 | (uint32_t)p2 << 8 | (uint32_t)p1 << 16 | (uint32_t)p0 << 24;
+    rowp[1] = (uint32_t)q0 | (uint32_t)q1 << 8 | (uint32_t)q2 << 16 | (uint32_t)q3 << 24;
+  } else if (any0) {
     // ---- vertical edges: line = row li, samples -4..15 (chroma -4..7) ------------------------------------------
     LDS uint32_t* rowp = (LDS uint32_t*) (chroma ? &L.C[cpl][tC (li, -4)] : &L.T[tY (li, -4)]);
     uint32_t w[5];
@@ -1023,6 +1037,8 @@ __device__ LH264_PHASE void deblock_phase (LDS WaveLds& L, const LDS WgLds& G, R
     for (int i = 0; i < 20; i++) v[i] = BYTE (w[i >> 2], i & 3);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+      // (scalar; the chroma lines take the strengths of luma edge 2 for their edge 1)
+      if ((((k == 1 ? live | live >> 4 : live) >> (4 * k)) & 15u) == 0) continue;
       // chroma edge k (k < 2) lies on luma edge 2k; chroma has no edges 2, 3
       const uint32_t bl = k == 0 ? bs0.x : k == 1 ? bs0.y : k == 2 ? bs0.z : bs0.w;
       const uint32_t bc = k == 0 ? bs0.x : k == 1 ? bs0.z : 0u;
@@ -1039,7 +1055,23 @@ __device__ LH264_PHASE void deblock_phase (LDS WaveLds& L, const LDS WgLds& G, R
     if (!chroma) { rowp[3] = w[3]; rowp[4] = w[4]; }
   }
   wsync();
-  if (any1) {
+  if (any1 && (live & 0xfff00000u) == 0) {
+    // ---- horizontal edges, only the macroblock edge is live: rows -4..3 of the column (chroma: -2..1) --------------------------------
+    int p3 = 0, p2 = 0, p1, p0, q0, q1, q2 = 0, q3 = 0;
+    const int bs = (int) ((bs1.x >> sh8) & 0xff);
+    const int tc0 = (int) ((tct >> (8 * (bs & 3))) & 0xff);
+    if (chroma) {
+      LDS uint8_t* cp = &L.C[cpl][tC (-2, li)];
+      p1 = cp[0]; p0 = cp[16]; q0 = cp[32]; q1 = cp[48];
+      filter_edge (p3, p2, p1, p0, q0, q1, q2, q3, (alt | bet) ? bs : 0, alt, bet, tc0, true);
+      cp[16] = (uint8_t)p0; cp[32] = (uint8_t)q0;
+    } else {
+      LDS uint8_t* cp = &L.T[tY (-4, li)];
+      p3 = cp[0]; p2 = cp[32]; p1 = cp[64]; p0 = cp[96]; q0 = cp[128]; q1 = cp[160]; q2 = cp[192]; q3 = cp[224];
+      filter_edge (p3, p2, p1, p0, q0, q1, q2, q3, (alt | bet) ? bs : 0, alt, bet, tc0, false);
+      cp[32] = (uint8_t)p2; cp[64] = (uint8_t)p1; cp[96] = (uint8_t)p0; cp[128] = (uint8_t)q0; cp[160] = (uint8_t)q1; cp[192] = (uint8_t)q2;
+    }
+  } else if (any1) {
     // ---- horizontal edges: line = column li, luma rows -4..15 = v[0..19], chroma rows -2..7 = v[2..11] -----------
     LDS uint8_t* colp = chroma ? &L.C[cpl][tC (-2, li)] : &L.T[tY (-4, li)];
 #pragma unroll
@@ -1049,6 +1081,7 @@ __device__ LH264_PHASE void deblock_phase (LDS WaveLds& L, const LDS WgLds& G, R
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+      if ((((k == 1 ? live | live >> 4 : live) >> (16 + 4 * k)) & 15u) == 0) continue;      // (scalar)
       const uint32_t bl = k == 0 ? bs1.x : k == 1 ? bs1.y : k == 2 ? bs1.z : bs1.w;
       const uint32_t bc = k == 0 ? bs1.x : k == 1 ? bs1.z : 0u;
       const int bs = (int) (((chroma ? bc : bl) >> sh8) & 0xff);
