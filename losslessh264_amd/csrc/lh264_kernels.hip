@@ -932,39 +932,36 @@ __device__ __forceinline__ int compute_bs (RecView m, RecView nb, bool have_nb, 
 // (deblocking_common.cpp:5-83); chroma: DeblockChromaLt4_c / DeblockChromaEq4_c (:85-140), which only touch p0/q0 and
 // use tc0+1.  One routine for both so that the luma lanes (0..15) and the chroma lanes (16..31) of a wave run the same
 // instruction stream.  Every formula uses the samples as they were before this edge.
+// Written without divergent branches: the lanes of a wave hold different lines with different strengths, so a branch per condition
+// is a chain of exec-mask saves and restores around a few instructions each; here the normal filter is computed for every lane and
+// selected, the strong one (bS 4: macroblock edges of intra macroblocks only) behind one wave-uniform branch.
+__device__ __forceinline__ int absd (int a, int b) { return (int)__builtin_amdgcn_sad_u16 ((uint32_t)a, (uint32_t)b, 0u); }    // samples: 0..255
 __device__ __forceinline__ void filter_edge (int& rp3, int& rp2, int& rp1, int& rp0, int& rq0, int& rq1, int& rq2, int& rq3,
                                              int bs, int alpha, int beta, int tc0, bool chroma) {
-  if (bs == 0) return;
   const int p3 = rp3, p2 = rp2, p1 = rp1, p0 = rp0, q0 = rq0, q1 = rq1, q2 = rq2, q3 = rq3;
-  const int d = abs (p0 - q0);
-  if (!(d < alpha && abs (p1 - p0) < beta && abs (q1 - q0) < beta)) return;
-  if (bs == 4) {
-    if (!chroma && d < ((alpha >> 2) + 2)) {
-      if (abs (p2 - p0) < beta) {
-        rp0 = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
-        rp1 = (p2 + p1 + p0 + q0 + 2) >> 2;
-        rp2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-      } else rp0 = (2 * p1 + p0 + q1 + 2) >> 2;
-      if (abs (q2 - q0) < beta) {
-        rq0 = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
-        rq1 = (p0 + q0 + q1 + q2 + 2) >> 2;
-        rq2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-      } else rq0 = (2 * q1 + q0 + p1 + 2) >> 2;
-    } else {
-      rp0 = (2 * p1 + p0 + q1 + 2) >> 2;
-      rq0 = (2 * q1 + q0 + p1 + 2) >> 2;
-    }
-  } else {
-    int t = tc0;
-    if (chroma) t = tc0 + 1;
-    else {
-      if (abs (p2 - p0) < beta) { rp1 = p1 + clip3 ((p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1, -tc0, tc0); t++; }
-      if (abs (q2 - q0) < beta) { rq1 = q1 + clip3 ((q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1, -tc0, tc0); t++; }
-    }
-    const int dl = clip3 ((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -t, t);
-    rp0 = clip_u8 (p0 + dl);
-    rq0 = clip_u8 (q0 - dl);
+  const int d = absd (p0, q0);
+  const bool on = bs != 0 && d < alpha && absd (p1, p0) < beta && absd (q1, q0) < beta;
+  const bool ap = !chroma && absd (p2, p0) < beta, aq = !chroma && absd (q2, q0) < beta;
+  // bS < 4
+  const int t = chroma ? tc0 + 1 : tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+  const int dl = clip3 ((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -t, t);
+  const int avg = (p0 + q0 + 1) >> 1;
+  int np0 = clip_u8 (p0 + dl), nq0 = clip_u8 (q0 - dl);
+  int np1 = ap ? p1 + clip3 ((p2 + avg - (p1 << 1)) >> 1, -tc0, tc0) : p1;
+  int nq1 = aq ? q1 + clip3 ((q2 + avg - (q1 << 1)) >> 1, -tc0, tc0) : q1;
+  int np2 = p2, nq2 = q2;
+  if (__ballot (on && bs == 4)) {                   // wave-uniform
+    const bool small = !chroma && d < ((alpha >> 2) + 2);
+    const bool sp = small && ap, sq = small && aq;
+    const int s4 = bs == 4;
+    const int wp0 = (2 * p1 + p0 + q1 + 2) >> 2, wq0 = (2 * q1 + q0 + p1 + 2) >> 2;
+    const int xp0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : wp0;
+    const int xq0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : wq0;
+    const int xp1 = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1, xq1 = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
+    const int xp2 = sp ? (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2, xq2 = sq ? (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
+    np0 = s4 ? xp0 : np0; nq0 = s4 ? xq0 : nq0; np1 = s4 ? xp1 : np1; nq1 = s4 ? xq1 : nq1; np2 = s4 ? xp2 : np2; nq2 = s4 ? xq2 : nq2;
   }
+  rp0 = on ? np0 : p0; rq0 = on ? nq0 : q0; rp1 = on ? np1 : p1; rq1 = on ? nq1 : q1; rp2 = on ? np2 : p2; rq2 = on ? nq2 : q2;
 }
 
 // WelsDeblockingMb (deblocking.cpp:815-862) + FilteringEdgeLumaHV / FilteringEdgeChromaHV (:568-700): the macroblock's
