@@ -21,7 +21,7 @@ int type_code (uint32_t t) {          // MacroblockModel::encodeMacroblockType M
 uint32_t rd32 (const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 
 struct Out {
-  std::vector<lh264_ctx_sym_t>& v;
+  PoolVec<lh264_ctx_sym_t>& v;
   void put (int kind, int table, uint32_t index, int value, int tag) {
     lh264_ctx_sym_t s; s.prior = LH264_PRIOR (table, index); s.value = (int16_t)value; s.kind = (uint8_t)kind; s.pad = (uint8_t)tag;
     v.push_back (s);
@@ -58,7 +58,8 @@ void Symbolizer::picture (FrameOut& f) {
   const int w = f.mb_w, n = f.mb_w * f.mb_h;
   if ((int)ipm_.size() != n * 8) { ipm_.assign ((size_t)n * 8, 0); nxn_.assign (n, 0); }
   // symbols in coding order; a macroblock's run is [start, start + cnt)
-  std::vector<lh264_ctx_sym_t>& flat = flat_; flat.clear();
+  // straight into the picture's list: slices in raster order (all but ASO streams) leave it in macroblock order already
+  PoolVec<lh264_ctx_sym_t>& flat = f.syn_syms; flat.clear();
   start_.assign (n, 0); cnt_.assign (n, 0);
   for (size_t si = 0; si < f.slices.size(); si++) {
     const lh264_slice_t& S = f.slices[si];
@@ -79,7 +80,7 @@ void Symbolizer::picture (FrameOut& f) {
     for (int k = S.first_mb; k < end && k < n; k++, mb_in_slice++) {
       Out o = {flat};
       start_[k] = (uint32_t)flat.size();
-      struct Close { std::vector<lh264_ctx_sym_t>& v; uint32_t& s; uint32_t& c; ~Close() { c = (uint32_t)v.size() - s; } } close_run = {flat, start_[k], cnt_[k]};
+      struct Close { PoolVec<lh264_ctx_sym_t>& v; uint32_t& s; uint32_t& c; ~Close() { c = (uint32_t)v.size() - s; } } close_run = {flat, start_[k], cnt_[k]};
       const int x = k % w;
       const Cell* nl = (x > 0 && cur[k - 1].initialized) ? &cur[k - 1] : nullptr;              // Neighbors::init MM:9-44
       const Cell* na = (k >= w && cur[k - w].initialized) ? &cur[k - w] : nullptr;
@@ -232,11 +233,20 @@ void Symbolizer::picture (FrameOut& f) {
     }
   }
   f.syn_off.assign ((size_t)n + 1, 0);
+  bool in_order = true;
+  uint32_t off = 0;
+  for (int k = 0; k < n; k++) {
+    if (cnt_[k] && start_[k] != off) { in_order = false; break; }
+    f.syn_off[k] = off;
+    off += cnt_[k];
+  }
+  if (in_order && off == flat.size()) { f.syn_off[n] = off; return; }
+  // slices out of raster order: the runs are put into macroblock order
+  flat_.assign (flat.begin(), flat.end());
   f.syn_syms.clear();
-  f.syn_syms.reserve (flat.size());
   for (int k = 0; k < n; k++) {
     f.syn_off[k] = (uint32_t)f.syn_syms.size();
-    f.syn_syms.insert (f.syn_syms.end(), flat.begin() + start_[k], flat.begin() + start_[k] + cnt_[k]);
+    f.syn_syms.insert (f.syn_syms.end(), flat_.begin() + start_[k], flat_.begin() + start_[k] + cnt_[k]);
   }
   f.syn_off[n] = (uint32_t)f.syn_syms.size();
 }
