@@ -10,6 +10,6 @@ from .recon import ReconSession  # noqa: F401
 from .ctx import CtxSession, past_policy  # noqa: F401
 from .parse import parse_stream, parse_file, parse_batch_time  # noqa: F401
 from .coder import CoderSession  # noqa: F401
-from .restore import restore, restore_batch, pack, restore_file, VERBATIM, compress_batch  # noqa: F401
+from .restore import restore, restore_batch, pack, restore_file, VERBATIM, compress_batch, compress_batch_handles  # noqa: F401
 
-__all__ = ["lib", "LibraryMissing", "ReconSession", "CtxSession", "past_policy", "parse_stream", "parse_file", "CoderSession", "restore", "restore_batch", "pack", "restore_file", "VERBATIM", "compress_batch", "parse_batch_time", "MB_DTYPE", "SLICE_DTYPE", "JOB_DTYPE", "pic_geometry"]
+__all__ = ["lib", "LibraryMissing", "ReconSession", "CtxSession", "past_policy", "parse_stream", "parse_file", "CoderSession", "restore", "restore_batch", "pack", "restore_file", "VERBATIM", "compress_batch", "compress_batch_handles", "parse_batch_time", "MB_DTYPE", "SLICE_DTYPE", "JOB_DTYPE", "pic_geometry"]

@@ -103,23 +103,17 @@ def restore_file(blob, size_hint=None):
     raise RuntimeError("restore failed: " + lib.lh264_restore_error().decode())
 
 
-def compress_batch(datas, threads=0, devices=None):
-    """the whole compress direction behind one C call (lh264_compress_batch): list of Annex-B byte strings ->
-    list of (main bytes, {tag: bytes}, error text or None).  devices: list of device indices to shard the batch over
-    (lh264_compress_batch_devices); default: the current device"""
-    lib = L.lib()
-    n = len(datas)
-    ptrs = (C.c_char_p * n)(*[bytes(d) for d in datas])
-    lens = (C.c_size_t * n)(*[len(d) for d in datas])
-    outs = (C.c_void_p * n)()
-    if devices:
-        devs = (C.c_int * len(devices))(*devices)
-        L.check(lib.lh264_compress_batch_devices(ptrs, lens, n, threads, devs, len(devices), outs))
-    else:
-        L.check(lib.lh264_compress_batch(ptrs, lens, n, threads, outs))
-    res = []
-    for i in range(n):
-        h = outs[i]
+class CompressedBatch:
+    """the handles lh264_compress_batch returned: results are copied out stream by stream on demand (the C call itself does not touch
+    Python objects: `seconds` is its wall time)"""
+
+    def __init__(self, handles, n, seconds):
+        self._h, self.n, self.seconds = handles, n, seconds
+
+    def result(self, i):
+        """-> (main bytes, {tag: bytes}, error text or None) of stream i"""
+        lib = L.lib()
+        h = self._h[i]
         ln = C.c_size_t(0)
         p = lib.lh264_compressed_main(h, C.byref(ln))
         main = C.string_at(p, ln.value) if ln.value else b""
@@ -129,6 +123,50 @@ def compress_batch(datas, threads=0, devices=None):
             if p:
                 tags[t] = C.string_at(p, ln.value)
         err = None if lib.lh264_compressed_status(h) == 0 else lib.lh264_compressed_error(h).decode()
-        res.append((main, tags, err))
-        lib.lh264_compressed_free(h)
+        return main, tags, err
+
+    def status(self, i):
+        return L.lib().lh264_compressed_status(self._h[i])
+
+    def free(self):
+        lib = L.lib()
+        for i in range(self.n):
+            if self._h[i]:
+                lib.lh264_compressed_free(self._h[i])
+                self._h[i] = None
+        self.n = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def compress_batch_handles(datas, threads=0, devices=None):
+    """lh264_compress_batch / lh264_compress_batch_devices -> CompressedBatch (call .free() when done)"""
+    import time
+    lib = L.lib()
+    n = len(datas)
+    ptrs = (C.c_char_p * n)(*[bytes(d) for d in datas])
+    lens = (C.c_size_t * n)(*[len(d) for d in datas])
+    outs = (C.c_void_p * n)()
+    t0 = time.perf_counter()
+    if devices:
+        devs = (C.c_int * len(devices))(*devices)
+        rc = lib.lh264_compress_batch_devices(ptrs, lens, n, threads, devs, len(devices), outs)
+    else:
+        rc = lib.lh264_compress_batch(ptrs, lens, n, threads, outs)
+    dt = time.perf_counter() - t0
+    L.check(rc)
+    return CompressedBatch(outs, n, dt)
+
+
+def compress_batch(datas, threads=0, devices=None):
+    """the whole compress direction behind one C call (lh264_compress_batch): list of Annex-B byte strings ->
+    list of (main bytes, {tag: bytes}, error text or None).  devices: list of device indices to shard the batch over
+    (lh264_compress_batch_devices); default: the current device"""
+    b = compress_batch_handles(datas, threads, devices)
+    res = [b.result(i) for i in range(b.n)]
+    b.free()
     return res
