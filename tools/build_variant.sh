@@ -6,6 +6,8 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build/variants
 C=losslessh264_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DLH264_MIN_WAVES=4 -Iinclude "$@" \
+W="-DLH264_MIN_WAVES=4"           # the product's register cap, unless the variant sets its own
+case "$*" in *LH264_MIN_WAVES*) W="";; esac
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value $W -Iinclude "$@" \
   $C/lh264_kernels.hip $C/lh264_ctx.hip $C/lh264_coder.hip $C/lh264_capi.hip $C/lh264_compress.hip $C/host/h264_parser.cpp $C/host/isvc_shim.cpp $C/host/pip_symbols.cpp $C/host/pip_restore.cpp -pthread -o build/variants/lib$name.so
 echo built build/variants/lib$name.so

@@ -22,7 +22,27 @@ def overlapped():
         sess.run()
     ctx.run(); coder.run()
     torch.cuda.current_stream(dev).wait_stream(s2)
-for name, fn in (("one stream", serial), ("two streams", overlapped), ("one stream", serial), ("two streams", overlapped)):
+def recon_second():
+    cur = torch.cuda.current_stream(dev)
+    ctx.run()
+    s2.wait_stream(cur)
+    with torch.cuda.stream(s2):
+        sess.run()
+    coder.run()
+    cur.wait_stream(s2)
+def recon_last():
+    cur = torch.cuda.current_stream(dev)
+    s2.wait_stream(cur)          # (the previous step's end)
+    ctx.run(); coder.run()
+    with torch.cuda.stream(s2):
+        sess.run()
+    cur.wait_stream(s2)
+def free_running():
+    # no join per step: the reconstruct stream runs ahead of (or behind) the coder stream; joined by the caller's synchronize
+    with torch.cuda.stream(s2):
+        sess.run()
+    ctx.run(); coder.run()
+for name, fn in (("one stream", serial), ("two streams", overlapped), ("recon second", recon_second), ("recon last", recon_last), ("two streams", overlapped), ("recon second", recon_second), ("recon last", recon_last)):
     fn(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(5):
