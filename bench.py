@@ -229,9 +229,10 @@ def main():
     k_ms = {"recon": 0.0, "ctx": 0.0, "coder": 0.0}
 
     # The reconstruct kernel (rows a1-a7) and the context-index + coder stages (a8-a10) read and write different buffers: a step
-    # launches them on two HIP streams and joins them at its end.  The reconstruct kernel is bound by vector-ALU issue, the coder by
-    # two serial chains whose waves mostly wait: side by side they fill each other's gaps.  (Per-stage times are taken from extra
-    # steps run on one stream, below.)
+    # launches them on two HIP streams and joins them at its end (31.5 -> 28.4 ms).  What overlaps is the reconstruct kernel and the
+    # binarisation (small workgroups that fit beside it); the resolve kernel does not fit beside two reconstruct workgroups per CU
+    # (80 KB of LDS and 97 registers per lane against 84 KB and 4 x 104 taken) and runs behind them - tools/overlap_timeline.py shows
+    # it.  (Per-stage times are taken from extra steps run on one stream, below.)
     side = torch.cuda.Stream(dev)
 
     def step(timed=False):
@@ -246,12 +247,11 @@ def main():
             ev[3].record()
             return
         side.wait_stream(cur)   # (the end of the step before)
-        ctx.run()       # row a8: per-coefficient context-model prior indices
-        coder.run()     # rows a9/a10: binarisation, adaptive probabilities, bool coders -> the tagged byte streams
+        ctx.run()               # row a8: per-coefficient context-model prior indices
+        coder.run()             # rows a9/a10: binarisation, adaptive probabilities, bool coders -> the tagged byte streams
         with torch.cuda.stream(side):
-            sess.run()  # rows a1-a7: reconstruct + deblock + pad (one launch of the dominant kernel); enqueued last, it starts at once:
-                        # coder.run() returns when its counting kernels are done and the rest is queued (measured: 28.3 ms against 28.8
-                        # with the reconstruct kernel enqueued first, 31.5 on one stream)
+            sess.run()          # rows a1-a7: reconstruct + deblock + pad (one launch of the dominant kernel); enqueued last, it starts at
+                                # once: coder.run() returns when its counting kernels are done and the rest is queued
         cur.wait_stream(side)
 
     for _ in range(args.warmup):

@@ -265,6 +265,14 @@ typedef struct lh264_code_stream {
  * when hip_stream has drained.  out_len_dev[LH264_N_TAG_SLOTS] != 0 reports 1: prior table full, 4: output overflow, 8: counter overflow. */
 int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
                        int n_chains, int n_jobs, long long total_mbs, int max_mbs_per_frame, void* hip_stream);
+/* The same in two calls, for a caller that wants to put other work between the halves (the second half - the adaptive probabilities
+ * and the bool coders - is two serial chains whose waves mostly wait: it runs well beside a kernel that is bound by arithmetic,
+ * e.g. lh264_recon_chains on another stream; the first half - binarisation - does not).  lh264_code_binarise_chains counts and
+ * writes the decision words (it is the half that synchronises hip_stream once); lh264_code_finish_chains must follow on the same
+ * device with the same streams_dev and n_chains, before any other coder call there. */
+int lh264_code_binarise_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
+                                int n_chains, int n_jobs, long long total_mbs, int max_mbs_per_frame, void* hip_stream);
+int lh264_code_finish_chains (const lh264_code_stream_t* streams_dev, int n_chains, void* hip_stream);
 /* sizes of the last lh264_code_chains call on the current device: 64-bit decision words written and read between its stages (one
  * per binary decision, each stream's count rounded up to 64) and 16-bit tag-list entries (one per decision, each tag's list padded
  * to 8): what the coder's memory traffic is computed from (bench.py). */

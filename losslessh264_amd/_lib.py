@@ -101,6 +101,8 @@ CODE_STREAM_DTYPE = np.dtype([("hash_keys", "<u8"), ("hash_cells", "<u8"), ("out
 N_TAG_SLOTS = 40
 assert CODE_JOB_DTYPE.itemsize == 40 and CODE_STREAM_DTYPE.itemsize == 40
 _SIGS["lh264_code_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_void_p])
+_SIGS["lh264_code_binarise_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_void_p])
+_SIGS["lh264_code_finish_chains"] = (C.c_int, [C.c_void_p, C.c_int, C.c_void_p])
 _SIGS["lh264_code_last_totals"] = (C.c_int, [C.c_void_p, C.c_void_p])
 EXPORTS = sorted(_SIGS)
 

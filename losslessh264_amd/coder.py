@@ -74,6 +74,17 @@ class CoderSession:
                                            self.ctx.n_jobs, self.ctx.n_mbs_total, self.ctx.max_mbs,
                                            self.torch.cuda.current_stream(self.ctx.dev).cuda_stream))
 
+    def binarise(self):
+        """first half of run(): count, scan, emit the decision words (lh264_code_binarise_chains; synchronises the stream once)"""
+        self.d_cells.zero_()
+        L.check(self.lib.lh264_code_binarise_chains(self.d_jobs.data_ptr(), self.ctx.d_first.data_ptr(), self.d_streams.data_ptr(), self.n_chains,
+                                                    self.ctx.n_jobs, self.ctx.n_mbs_total, self.ctx.max_mbs,
+                                                    self.torch.cuda.current_stream(self.ctx.dev).cuda_stream))
+
+    def finish(self):
+        """second half of run(): adaptive probabilities and bool coders (lh264_code_finish_chains)"""
+        L.check(self.lib.lh264_code_finish_chains(self.d_streams.data_ptr(), self.n_chains, self.torch.cuda.current_stream(self.ctx.dev).cuda_stream))
+
     def tags(self, chain):
         """-> {tag: bytes} of one stream (after run + synchronize)"""
         n = L.N_TAG_SLOTS

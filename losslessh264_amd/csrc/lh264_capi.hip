@@ -189,6 +189,10 @@ struct CoderWs {
   void* big = nullptr; size_t big_cap = 0;         // decision words + tag lists
   unsigned long long* totals_host = nullptr;       // page-locked, 2 x u64
   unsigned long long last_words = 0, last_q = 0;   // of the last call: decisions (incl. per-stream padding to 64), list entries
+  // what lh264_code_binarise_chains leaves for lh264_code_finish_chains
+  int ready_chains = -1, n_pairs = 0; size_t chunk_bound = 0; const lh264_code_stream_t* ready_streams = nullptr;
+  uint32_t* info = nullptr; uint64_t* D = nullptr; uint16_t* Q = nullptr;
+  uint32_t* pair_chunk0 = nullptr; uint32_t* pair_bits = nullptr; uint32_t* chunk_rec = nullptr; uint32_t* acc = nullptr;
 };
 CoderWs g_coder_ws[16];
 int grow (void** p, size_t* cap, size_t need) {
@@ -203,17 +207,11 @@ int grow (void** p, size_t* cap, size_t need) {
 size_t up256 (size_t v) { return (v + 255) & ~ (size_t)255; }
 }
 
-int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
-                       int n_chains, int n_jobs, long long total_mbs, int max_mbs_per_frame, void* stream) {
-  if (lh264_device_count() <= 0) return fail (LH264_E_NODEVICE, "no HIP device visible");
-  if (!jobs_dev || !chain_first_dev || !streams_dev || n_chains < 0 || n_jobs < 0 || total_mbs < 0 || max_mbs_per_frame <= 0) return fail (LH264_E_ARG, "bad argument");
-  if (n_chains == 0) return LH264_OK;
-  int dev = 0;
-  HIPCHK (hipGetDevice (&dev));
-  if (dev < 0 || dev >= 16) return fail (LH264_E_ARG, "device index out of range");
-  CoderWs& W = g_coder_ws[dev];
-  std::lock_guard<std::mutex> lock (W.mu);
-  hipStream_t st = (hipStream_t)stream;
+// the two halves of lh264_code_chains: binarise (count, scan, bases, one synchronisation for the sizes, emit) and code (resolve, range,
+// accumulate, bytes).  What the second half needs of the first is kept in the device's work space.
+static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
+                          int n_chains, int n_jobs, long long total_mbs, hipStream_t st) {
+  W.ready_chains = -1;
   if (!W.totals_host) HIPCHK (hipHostMalloc ((void**)&W.totals_host, 2 * sizeof (unsigned long long), hipHostMallocDefault));
   // small tables.  A picture of n macroblocks is cut into ceil (n / LH264_CODER_SEG_MBS) segments
   const size_t seg_bound = (size_t)total_mbs / LH264_CODER_SEG_MBS + (size_t)n_jobs + 1;
@@ -224,7 +222,6 @@ int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_fi
   uint8_t* sm = (uint8_t*)W.small;
   uint32_t* seg0 = (uint32_t*) (sm + o_seg0); uint32_t* job_chain = (uint32_t*) (sm + o_jobchain); uint32_t* info = (uint32_t*) (sm + o_info);
   unsigned long long* totals = (unsigned long long*) (sm + o_totals); uint32_t* seg_doff = (uint32_t*) (sm + o_doff); uint32_t* seg_cnt = (uint32_t*) (sm + o_cnt);
-  (void)max_mbs_per_frame;
   hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, seg0, job_chain, info);
   HIPCHK (hipGetLastError());
   if (n_jobs > 0 && total_mbs > 0) {
@@ -257,6 +254,18 @@ int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_fi
     hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, job_chain, n_jobs, seg_doff, info, D);
     HIPCHK (hipGetLastError());
   }
+  W.info = info; W.D = D; W.Q = Q; W.pair_chunk0 = pair_chunk0; W.pair_bits = pair_bits; W.chunk_rec = chunk_rec; W.acc = acc;
+  W.chunk_bound = chunk_bound; W.n_pairs = n_pairs; W.ready_chains = n_chains; W.ready_streams = streams_dev;
+  W.last_words = n_words; W.last_q = n_q;
+  return LH264_OK;
+}
+
+static int code_finish (CoderWs& W, const lh264_code_stream_t* streams_dev, int n_chains, hipStream_t st) {
+  if (W.ready_chains != n_chains || W.ready_streams != streams_dev) return fail (LH264_E_ARG, "lh264_code_finish_chains without the matching lh264_code_binarise_chains");
+  uint32_t* info = W.info; uint64_t* D = W.D; uint16_t* Q = W.Q; uint32_t* pair_chunk0 = W.pair_chunk0; uint32_t* pair_bits = W.pair_bits;
+  uint32_t* chunk_rec = W.chunk_rec; uint32_t* acc = W.acc;
+  const size_t chunk_bound = W.chunk_bound; const int n_pairs = W.n_pairs;
+  W.ready_chains = -1;
   hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 (n_chains), dim3 (LH264_CODER_RESOLVE_THREADS), 0, st, streams_dev, info, D, Q, n_chains);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_status_kernel, dim3 ((n_chains + 255) / 256), dim3 (256), 0, st, streams_dev, info, n_chains);
@@ -270,9 +279,49 @@ int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_fi
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_bytes_kernel, dim3 ((unsigned) ((n_pairs + 63) / 64)), dim3 (64), 0, st, streams_dev, info, Q, pair_bits, acc, n_pairs);
   HIPCHK (hipGetLastError());
-  W.last_words = n_words; W.last_q = n_q;
   // tag slots 35 .. LH264_N_TAG_SLOTS-1 do not exist: their lengths read 0
   return LH264_OK;
+}
+
+
+static int coder_ws (CoderWs** W) {
+  if (lh264_device_count() <= 0) return fail (LH264_E_NODEVICE, "no HIP device visible");
+  int dev = 0;
+  HIPCHK (hipGetDevice (&dev));
+  if (dev < 0 || dev >= 16) return fail (LH264_E_ARG, "device index out of range");
+  *W = &g_coder_ws[dev];
+  return LH264_OK;
+}
+static bool code_args_ok (const void* jobs_dev, const void* chain_first_dev, const void* streams_dev, int n_chains, int n_jobs, long long total_mbs, int max_mbs_per_frame) {
+  return jobs_dev && chain_first_dev && streams_dev && n_chains >= 0 && n_jobs >= 0 && total_mbs >= 0 && max_mbs_per_frame > 0;
+}
+
+int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
+                       int n_chains, int n_jobs, long long total_mbs, int max_mbs_per_frame, void* stream) {
+  CoderWs* W = nullptr;
+  if (int rc = coder_ws (&W)) return rc;
+  if (!code_args_ok (jobs_dev, chain_first_dev, streams_dev, n_chains, n_jobs, total_mbs, max_mbs_per_frame)) return fail (LH264_E_ARG, "bad argument");
+  if (n_chains == 0) return LH264_OK;
+  std::lock_guard<std::mutex> lock (W->mu);
+  if (int rc = code_binarise (*W, jobs_dev, chain_first_dev, streams_dev, n_chains, n_jobs, total_mbs, (hipStream_t)stream)) return rc;
+  return code_finish (*W, streams_dev, n_chains, (hipStream_t)stream);
+}
+int lh264_code_binarise_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
+                                int n_chains, int n_jobs, long long total_mbs, int max_mbs_per_frame, void* stream) {
+  CoderWs* W = nullptr;
+  if (int rc = coder_ws (&W)) return rc;
+  if (!code_args_ok (jobs_dev, chain_first_dev, streams_dev, n_chains, n_jobs, total_mbs, max_mbs_per_frame)) return fail (LH264_E_ARG, "bad argument");
+  if (n_chains == 0) return LH264_OK;
+  std::lock_guard<std::mutex> lock (W->mu);
+  return code_binarise (*W, jobs_dev, chain_first_dev, streams_dev, n_chains, n_jobs, total_mbs, (hipStream_t)stream);
+}
+int lh264_code_finish_chains (const lh264_code_stream_t* streams_dev, int n_chains, void* stream) {
+  CoderWs* W = nullptr;
+  if (int rc = coder_ws (&W)) return rc;
+  if (!streams_dev || n_chains < 0) return fail (LH264_E_ARG, "bad argument");
+  if (n_chains == 0) return LH264_OK;
+  std::lock_guard<std::mutex> lock (W->mu);
+  return code_finish (*W, streams_dev, n_chains, (hipStream_t)stream);
 }
 
 int lh264_code_last_totals (unsigned long long* decision_words, unsigned long long* list_entries) {

@@ -625,9 +625,6 @@ __device__ __forceinline__ void rs_barrier() {
 // ahead; the cache entries of a round are looked up two steps before the round is resolved (a DynProb that is not in the cache is
 // inserted then, and its spilled counters requested); the answer goes into the entry one step later, BEFORE the wave's own turn of
 // that step - every round that uses the entry comes later in ticket order than that turn, so it sees the counters.
-#ifdef LH264_RS_WAVES_PER_EU
-__attribute__ ((amdgpu_waves_per_eu (LH264_RS_WAVES_PER_EU, LH264_RS_WAVES_PER_EU)))
-#endif
 __global__ void __launch_bounds__ (RS_WAVES * 64)
 coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t* __restrict__ chain_info, const uint64_t* __restrict__ D,
                       uint16_t* __restrict__ Q, int n_chains) {

@@ -86,6 +86,31 @@ def test_whole_stream_compress_equals_reference_cli_and_round_trips():
         assert lh.restore(mains[c], got) == datas[c], name
 
 
+def test_coder_in_two_calls_equals_one_call():
+    """lh264_code_binarise_chains + lh264_code_finish_chains (with another kernel on a second stream between them) == lh264_code_chains;
+    a finish without its binarise is refused"""
+    import torch
+    import losslessh264_amd as lh
+    names = ["SVA_BA1_B.264", "test_qcif_cabac.264"]
+    streams = [lh.parse_file(open(os.path.join(golden_io.GOLDEN_DIR, "streams", n), "rb").read())[0] for n in names]
+    ctx = lh.CtxSession(streams, replicate=3)
+    ctx.run()
+    coder = lh.CoderSession(ctx)
+    coder.run()
+    ctx.synchronize()
+    one = [coder.tags(c) for c in range(6)]
+    rec = lh.ReconSession(streams, replicate=3)
+    side = torch.cuda.Stream(ctx.dev)
+    coder.binarise()
+    with torch.cuda.stream(side):
+        rec.run()
+    coder.finish()
+    torch.cuda.synchronize(ctx.dev)
+    assert [coder.tags(c) for c in range(6)] == one
+    with pytest.raises(RuntimeError, match="without the matching"):
+        coder.finish()
+
+
 def test_command_line_compress_and_restore(tmp_path):
     """`python -m losslessh264_amd in.264 out.pip out.yuv` writes the reference console application's files (names and bytes), the
     YUV dump has the SHA-1 of the reference's decoder test, and `... out.pip back.264` gives the input back"""

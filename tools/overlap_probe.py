@@ -37,12 +37,34 @@ def recon_last():
     with torch.cuda.stream(s2):
         sess.run()
     cur.wait_stream(s2)
+def split_coder():
+    # the reconstruct kernel beside the second half of the coder only (lh264_code_binarise_chains / lh264_code_finish_chains)
+    cur = torch.cuda.current_stream(dev)
+    ctx.run(); coder.binarise()
+    s2.wait_stream(cur)
+    with torch.cuda.stream(s2):
+        sess.run()
+    coder.finish()
+    cur.wait_stream(s2)
+ev_emit = torch.cuda.Event()
+def split_recon_main():
+    # as split_coder, but the reconstruct kernel sits right behind the binarisation in the main queue and the coder's second half comes
+    # from the other one: the reconstruct workgroups are placed first (two per CU), the resolve workgroups take what is left
+    cur = torch.cuda.current_stream(dev)
+    s2.wait_stream(cur)
+    ctx.run(); coder.binarise()
+    ev_emit.record(cur)
+    sess.run()
+    s2.wait_event(ev_emit)
+    with torch.cuda.stream(s2):
+        coder.finish()
+    cur.wait_stream(s2)
 def free_running():
     # no join per step: the reconstruct stream runs ahead of (or behind) the coder stream; joined by the caller's synchronize
     with torch.cuda.stream(s2):
         sess.run()
     ctx.run(); coder.run()
-for name, fn in (("one stream", serial), ("two streams", overlapped), ("recon second", recon_second), ("recon last", recon_last), ("two streams", overlapped), ("recon second", recon_second), ("recon last", recon_last)):
+for name, fn in (("one stream", serial), ("two streams", overlapped), ("recon last", recon_last), ("split coder", split_coder), ("split rmain", split_recon_main), ("recon last", recon_last), ("split rmain", split_recon_main)):
     fn(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(5):

@@ -3,5 +3,5 @@
 cd /root/repo
 for v in build/variants/lib*.so; do
   echo "== $v"
-  LH264_SO=$PWD/$v timeout -k 10 200 python3 tools/overlap_probe.py 512 2>&1 | grep "stream"
+  LH264_SO=$PWD/$v timeout -k 10 200 python3 tools/overlap_probe.py 512 2>&1 | grep "stream\|recon\|split"
 done
