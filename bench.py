@@ -234,6 +234,7 @@ def main():
     # (80 KB of LDS and 97 registers per lane against 84 KB and 4 x 104 taken) and runs behind them - tools/overlap_timeline.py shows
     # it.  (Per-stage times are taken from extra steps run on one stream, below.)
     side = torch.cuda.Stream(dev)
+    recon_events = []
 
     def step(timed=False):
         cur = torch.cuda.current_stream(dev)
@@ -250,16 +251,23 @@ def main():
         ctx.run()               # row a8: per-coefficient context-model prior indices
         coder.run()             # rows a9/a10: binarisation, adaptive probabilities, bool coders -> the tagged byte streams
         with torch.cuda.stream(side):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()         # (on the stream the kernel is launched on: its duration in the timed steps, beside the coder)
             sess.run()          # rows a1-a7: reconstruct + deblock + pad (one launch of the dominant kernel); enqueued last, it starts at
                                 # once: coder.run() returns when its counting kernels are done and the rest is queued
+            e1.record()
+            recon_events.append((e0, e1))
         cur.wait_stream(side)
 
+    step(timed=True)            # untimed priming pass on one stream: the coder's work memory is allocated here, not beside the first kernel
+    torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    recon_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -285,7 +293,10 @@ def main():
     n_intra = int(np.count_nonzero(types & 0x207))
     n_inter = int(np.count_nonzero(types & 0x1F8))
     alg_bytes = (n_intra * INTRA_BYTES_PER_MB + n_inter * INTER_BYTES_PER_MB) * rep
-    achieved = alg_bytes / (k_ms["recon"] * 1e-3) / 1e9
+    # the dominant kernel's launch duration over the timed region (where it runs beside the coder's kernels); k_ms["recon"] is the same
+    # kernel with the machine to itself
+    recon_ms = sum(a.elapsed_time(b) for a, b in recon_events[:args.steps]) / max(1, min(args.steps, len(recon_events)))
+    achieved = alg_bytes / (recon_ms * 1e-3) / 1e9
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes from the
     # committed rocprofv3 --pmc passes over the same launch (profiles/traffic.json), corrected as the guide prescribes
@@ -416,7 +427,7 @@ def main():
                                      "measured_on_hardware": ("rehearsal: all ranks on GPU 0, gloo collectives - not a scaling measurement" if coll_dev is None and world > 1
                                                               else "this line" if world > 1 else "single GPU; N > 1 unmeasured in this run")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "recon_chain_kernel", "kernel_ms": k_ms["recon"], "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": traffic, "kernel": "recon_chain_kernel", "kernel_ms": recon_ms, "kernel_ms_alone": k_ms["recon"], "algorithmic_bytes_per_launch": alg_bytes,
                          "coder_stage": {"bound": "hbm", "achieved": coder_bytes / (k_ms["coder"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": coder_bytes / (k_ms["coder"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": k_ms["coder"], "algorithmic_bytes": coder_bytes, "traffic": coder_traffic,
                                          "note": "symbols read twice + 8-byte decision words and 2-byte list entries written and read once + output; "
