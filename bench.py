@@ -55,10 +55,25 @@ def spawn_ranks(args):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode()
-    rc = procs[0].returncode
-    for p in procs[1:]:
+    # a rank that dies (no such device, out of memory ...) must not leave the others waiting in a collective for ever
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad:
+            rc = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()            # (exactly the children started above)
+            break
+        time.sleep(0.2)
+    for p in procs:
         rc = rc or p.wait()
+    reader.join(timeout=10)
+    out = (buf[0] if buf else b"").decode()
     lines = [l for l in out.splitlines() if l.startswith("{")]        # (a collective library may chat on stdout)
     sys.stdout.write((lines[-1] if lines else out) + "\n")
     sys.exit(rc)
@@ -173,6 +188,7 @@ def main():
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: running %d rank(s)\n" % (args.gpus, world, world))
     dist = None
+    rehearse = False
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -188,6 +204,25 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     coll_dev = None if (world > 1 and os.environ.get("LH264_BENCH_REHEARSE") == "1") else dev
+    collectives = "none (one rank)" if world == 1 else ("gloo (rehearsal)" if coll_dev is None else "nccl (RCCL)")
+    if world > 1 and coll_dev is not None:
+        # the data path has no collective; RCCL carries the barrier, the max of the step times and the gathered result records.  If its
+        # first collective fails on this node, every rank sees the failure and they fall back together to gloo on host memory
+        try:
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize(dev)
+            assert int(probe.item()) == world
+        except Exception as e:                          # noqa: BLE001
+            sys.stderr.write("bench.py: RCCL collective failed on rank %d (%r): falling back to gloo for barrier / max / gather\n" % (rank, e))
+            try:
+                dist.destroy_process_group()
+            except Exception:                           # noqa: BLE001
+                pass
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            coll_dev = None
+            collectives = "gloo (RCCL failed on this node: %s)" % type(e).__name__
 
     cfg = CONFIGS[args.config]
     per_gpu = args.streams or cfg["n"]
@@ -423,8 +458,8 @@ def main():
                        "stage_ms": {"a1_a7_recon_chain_kernel": k_ms["recon"], "a8_ctx_kernels": k_ms["ctx"], "a9_a10_coder_kernels": k_ms["coder"]},
                        "a1_a8_only_MB_per_s": local_bytes / (a18 * 1e-3) / 1e6,
                        "compression": roundtrip, "host_stages": host_stages,
-                       "multi_gpu": {"result_records_gathered": n_records, "global_streams": n_global,
-                                     "measured_on_hardware": ("rehearsal: all ranks on GPU 0, gloo collectives - not a scaling measurement" if coll_dev is None and world > 1
+                       "multi_gpu": {"result_records_gathered": n_records, "global_streams": n_global, "collectives": collectives,
+                                     "measured_on_hardware": ("rehearsal: all ranks on GPU 0, gloo collectives - not a scaling measurement" if rehearse
                                                               else "this line" if world > 1 else "single GPU; N > 1 unmeasured in this run")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "recon_chain_kernel", "kernel_ms": recon_ms, "kernel_ms_alone": k_ms["recon"], "algorithmic_bytes_per_launch": alg_bytes,

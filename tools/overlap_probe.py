@@ -46,6 +46,23 @@ def split_coder():
         sess.run()
     coder.finish()
     cur.wait_stream(s2)
+halves = [lh.ReconSession([frames], replicate=streams // 2, share_records=False) for _ in range(2)] if os.environ.get("PROBE_HALVES") else None
+def recon_halves():
+    # the reconstruct batch as two launches of half the streams each (one workgroup per CU at a time): slower by itself, but the
+    # coder's kernels - the resolve kernel too - fit beside it
+    cur = torch.cuda.current_stream(dev)
+    s2.wait_stream(cur)
+    with torch.cuda.stream(s2):
+        halves[0].run(); halves[1].run()
+    ctx.run(); coder.run()
+    cur.wait_stream(s2)
+def recon_halves_last():
+    cur = torch.cuda.current_stream(dev)
+    s2.wait_stream(cur)
+    ctx.run(); coder.run()
+    with torch.cuda.stream(s2):
+        halves[0].run(); halves[1].run()
+    cur.wait_stream(s2)
 ev_emit = torch.cuda.Event()
 def split_recon_main():
     # as split_coder, but the reconstruct kernel sits right behind the binarisation in the main queue and the coder's second half comes
@@ -64,7 +81,10 @@ def free_running():
     with torch.cuda.stream(s2):
         sess.run()
     ctx.run(); coder.run()
-for name, fn in (("one stream", serial), ("two streams", overlapped), ("recon last", recon_last), ("split coder", split_coder), ("split rmain", split_recon_main), ("recon last", recon_last), ("split rmain", split_recon_main)):
+modes = (("one stream", serial), ("two streams", overlapped), ("recon last", recon_last), ("split coder", split_coder), ("split rmain", split_recon_main), ("recon last", recon_last))
+if halves:
+    modes = (("one stream", serial), ("recon last", recon_last), ("halves first", recon_halves), ("halves last", recon_halves_last), ("halves first", recon_halves), ("halves last", recon_halves_last))
+for name, fn in modes:
     fn(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(5):
