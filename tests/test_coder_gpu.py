@@ -53,6 +53,35 @@ def test_replicas_are_identical_and_rerun_is_stable():
         assert coder.tags(c) == ref
 
 
+def test_coder_reports_what_does_not_fit():
+    """an output buffer that is too small ends in status bit 4 (the other streams of the call are unharmed, nothing is written behind
+    a stream's buffers); a spill table of one cell either still gives the reference's bytes or reports status bit 1"""
+    import torch
+    import losslessh264_amd as lh
+    name = "SVA_BA1_B.264"
+    z = np.load(os.path.join(golden_io.GOLDEN_DIR, "pip_" + name + ".npz"))
+    ref = {int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")}
+    ctx = lh.CtxSession([_frames(name, z)], replicate=2)
+    ctx.run()
+    small = lh.CoderSession(ctx, out_cap=256)                         # the largest tag of this stream is a few KB
+    guard = small.d_out.clone()
+    small.run()
+    ctx.synchronize()
+    with pytest.raises(RuntimeError, match="status"):
+        small.tags(0)
+    n = lh._lib.N_TAG_SLOTS
+    lens = small.d_len.cpu().numpy().reshape(2, n + 1)
+    assert (lens[:, n] & 4).all() and (lens[:, :35].max(axis=1) > 256).all()      # the lengths say how much room was needed
+    del guard
+    tiny = lh.CoderSession(ctx, hash_cap=1)
+    tiny.run()
+    ctx.synchronize()
+    st = tiny.d_len.cpu().numpy().reshape(2, n + 1)[:, n]
+    assert ((st == 0) | ((st & 1) != 0)).all()
+    if (st == 0).all():
+        assert tiny.tags(0) == ref and tiny.tags(1) == ref
+
+
 # ---- whole streams: compress on the device, compare with the reference CLI's files, restore, compare with the input -----
 CLI = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(golden_io.GOLDEN_DIR, "cli_*.npz")))
 CLI_CAVLC = [n for n in CLI if "cabac" not in n.lower()]
