@@ -239,6 +239,7 @@ def main():
     # input bytes a stream stands for: the whole file, or the share of the pictures used
     full = [lh.parse_file(d)[0] for d in datas] if n_frames else distinct
     stream_bytes = [len(d) * sum(f.mb_w * f.mb_h for f in fr) / max(1, sum(f.mb_w * f.mb_h for f in fu)) for d, fr, fu in zip(datas, distinct, full)]
+    whole = [len(fr) == len(fu) for fr, fu in zip(distinct, full)]         # the stream is used as a whole: the reference's file sizes apply
     del full
     # ---- the global stream list and this rank's share (static partition by macroblock count, no exchange during work) ----------
     n_global = per_gpu * world
@@ -362,7 +363,7 @@ def main():
     ref_tagged = []
     for name in cfg["streams"]:
         p = os.path.join(ROOT, "tests", "golden", "cli_" + name + ".npz")
-        if os.path.exists(p) and not n_frames:
+        if os.path.exists(p) and whole[len(ref_tagged)]:
             z = np.load(p)
             ref_tagged.append(sum(len(z[k]) for k in z.files if k.startswith("tag_")))
         else:
@@ -383,7 +384,18 @@ def main():
         assert roundtrip["roundtrip_ok"], "restore(compress(stream)) differs from the stream"
     else:
         # ratio of what was coded: the tagged streams against the share of the input they stand for (the default stream is per file)
-        roundtrip = {"tagged_bytes_per_input_byte": float(coded_local.sum()) / max(1.0, local_bytes)}
+        roundtrip = {"tagged_bytes_per_input_byte": float(coded_local.sum()) / max(1.0, local_bytes),
+                     "coded_bytes_equal_reference_files": [w is not None for w in ref_tagged]}
+        if all(w is not None for w in ref_tagged):
+            # whole streams: size and round trip of one replica of every distinct stream, as for configs[1]
+            ok = True
+            for k in range(len(distinct)):
+                c = next(i for i in range(n_local) if (my_kinds[0] + i) % len(distinct) == k)
+                ok = ok and lh.restore(mains[k], coder.tags(c)) == datas[k]
+            z = [np.load(os.path.join(ROOT, "tests", "golden", "cli_" + name + ".npz")) for name in cfg["streams"]]
+            roundtrip.update({"ratio": sum(len(m) + w for m, w in zip(mains, ref_tagged)) / sum(len(d) for d in datas),
+                              "reference_ratio": sum(sum(len(q[f]) for f in q.files) for q in z) / sum(len(d) for d in datas), "roundtrip_ok": ok})
+            assert ok, "restore(compress(stream)) differs from the stream"
 
     # ---- multi-GPU: the per-stream result records of every rank, gathered and checked once on rank 0 ---------------------------------------
     outv = coder.d_out.view(n_local, -1)
