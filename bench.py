@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the host-stage (front end / restore / end-to-end) measurements")
+    ap.add_argument("--no-pipeline", action="store_true", help="every batch on its own: no second batch's context indexing beside the coder")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                                   # does not return
@@ -260,6 +261,15 @@ def main():
         out_cap <<= 1
     coder = lh.CoderSession(ctx, out_cap=out_cap)
     local_bytes = sum(stream_bytes[k] for k in my_kinds)
+    # Two batches in flight (a pipeline of depth two over the queue of batches a service works through): while batch i is binarised,
+    # reconstructed and coded, the context indices of batch j are computed on a third stream, behind the binarisation of i - beside the
+    # resolve kernel and the bool coder's kernels, whose waves mostly wait.  Every step still launches every kernel of rows a1-a10 once;
+    # the second batch is a second set of device buffers with the same streams (synthetic input).  Only where that second set fits easily.
+    pipeline = not args.no_pipeline and ctx.n_mbs_total * 4400 < 40e9
+    ctxs, coders = [ctx], [coder]
+    if pipeline:
+        ctxs.append(lh.CtxSession(order, device=local_rank, replicate=rep))
+        coders.append(lh.CoderSession(ctxs[1], out_cap=out_cap))
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     k_ms = {"recon": 0.0, "ctx": 0.0, "coder": 0.0}
@@ -270,7 +280,20 @@ def main():
     # (80 KB of LDS and 97 registers per lane against 84 KB and 4 x 104 taken) and runs behind them - tools/overlap_timeline.py shows
     # it.  (Per-stage times are taken from extra steps run on one stream, below.)
     side = torch.cuda.Stream(dev)
+    third = torch.cuda.Stream(dev)
+    ctx_done = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_binarised = torch.cuda.Event()
     recon_events = []
+    state = {"k": 0, "pipelined": False}
+
+    def recon_on_side():
+        with torch.cuda.stream(side):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()         # (on the stream the kernel is launched on: its duration in the timed steps, beside the coder)
+            sess.run()          # rows a1-a7: reconstruct + deblock + pad (one launch of the dominant kernel); enqueued behind the coder's
+                                # first half, it starts at once: that call returns when its counting kernels are done
+            e1.record()
+            recon_events.append((e0, e1))
 
     def step(timed=False):
         cur = torch.cuda.current_stream(dev)
@@ -284,19 +307,40 @@ def main():
             ev[3].record()
             return
         side.wait_stream(cur)   # (the end of the step before)
-        ctx.run()               # row a8: per-coefficient context-model prior indices
-        coder.run()             # rows a9/a10: binarisation, adaptive probabilities, bool coders -> the tagged byte streams
-        with torch.cuda.stream(side):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()         # (on the stream the kernel is launched on: its duration in the timed steps, beside the coder)
-            sess.run()          # rows a1-a7: reconstruct + deblock + pad (one launch of the dominant kernel); enqueued last, it starts at
-                                # once: coder.run() returns when its counting kernels are done and the rest is queued
-            e1.record()
-            recon_events.append((e0, e1))
+        if not state["pipelined"]:
+            ctx.run()           # row a8: per-coefficient context-model prior indices
+            coder.run()         # rows a9/a10: binarisation, adaptive probabilities, bool coders -> the tagged byte streams
+            recon_on_side()
+            cur.wait_stream(side)
+            return
+        i = state["k"] & 1
+        j = 1 - i
+        state["k"] += 1
+        cur.wait_event(ctx_done[i])                 # batch i's context indices (row a8), computed during the step before
+        coders[i].binarise()                        # rows a9/a10, first half, batch i
+        ev_binarised.record(cur)
+        recon_on_side()                             # rows a1-a7
+        third.wait_event(ev_binarised)
+        with torch.cuda.stream(third):
+            ctxs[j].run()                           # row a8 of the next batch
+            ctx_done[j].record(third)
+        coders[i].finish()                          # rows a9/a10, second half, batch i
         cur.wait_stream(side)
 
     step(timed=True)            # untimed priming pass on one stream: the coder's work memory is allocated here, not beside the first kernel
     torch.cuda.synchronize(dev)
+    # a few steps with every batch on its own (two streams, no second batch in flight): reported beside the pipelined figure
+    step()
+    torch.cuda.synchronize(dev)
+    t_u = time.perf_counter()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize(dev)
+    unpipelined_ms = (time.perf_counter() - t_u) / 3 * 1e3
+    if pipeline:
+        state["pipelined"] = True
+        ctxs[0].run()
+        ctx_done[0].record(torch.cuda.current_stream(dev))
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -317,6 +361,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    state["pipelined"] = False
+    torch.cuda.synchronize(dev)
     # per-stage device time, hipEvents on the launch stream (torch's current stream is the stream the C ABI launches on), a few extra steps
     n_ev = max(2, min(args.steps, 5))
     for _ in range(n_ev):
@@ -467,6 +513,9 @@ def main():
                                       "stream (adaptive probabilities), one lane per (stream, tag) (bool coder's range), one lane per 256 decisions (its sums); "
                                       "the reconstruct kernel runs on a second HIP stream beside the context-index and coder kernels; streams sharded across GPUs",
                        "stage_ms_note": "stage times are from steps run on one stream; in the timed steps the stages overlap, ms_per_step is less than their sum",
+                       "pipeline": ("two batches in flight: the context-index kernels (row a8) of the next batch run on a third HIP stream beside the second half of "
+                                    "this batch's coder; every step launches every kernel of rows a1-a10 once" if pipeline else "none: every batch on its own"),
+                       "ms_per_step_one_batch_in_flight": unpipelined_ms,
                        "stage_ms": {"a1_a7_recon_chain_kernel": k_ms["recon"], "a8_ctx_kernels": k_ms["ctx"], "a9_a10_coder_kernels": k_ms["coder"]},
                        "a1_a8_only_MB_per_s": local_bytes / (a18 * 1e-3) / 1e6,
                        "compression": roundtrip, "host_stages": host_stages,

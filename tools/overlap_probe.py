@@ -63,6 +63,47 @@ def recon_halves_last():
     with torch.cuda.stream(s2):
         halves[0].run(); halves[1].run()
     cur.wait_stream(s2)
+pipe = None
+if os.environ.get("PROBE_PIPE"):
+    # two batches in flight: while batch i is binarised, reconstructed and coded, the context indices of batch j are computed on a
+    # third stream (behind the binarisation of i: beside the resolve kernel and the bool coder's kernels)
+    ctx_b = lh.CtxSession([frames], replicate=streams)
+    coder_b = lh.CoderSession(ctx_b)
+    pipe = {"ctx": [ctx, ctx_b], "coder": [coder, coder_b], "done": [torch.cuda.Event(), torch.cuda.Event()], "ev": torch.cuda.Event(), "s3": torch.cuda.Stream(dev), "k": 0}
+    ctx.run(); pipe["done"][0].record(torch.cuda.current_stream(dev))
+def pipelined():
+    cur = torch.cuda.current_stream(dev)
+    i = pipe["k"] & 1; j = 1 - i
+    pipe["k"] += 1
+    s2.wait_stream(cur)
+    cur.wait_event(pipe["done"][i])
+    pipe["coder"][i].binarise()
+    pipe["ev"].record(cur)
+    with torch.cuda.stream(s2):
+        sess.run()
+    pipe["s3"].wait_event(pipe["ev"])
+    with torch.cuda.stream(pipe["s3"]):
+        pipe["ctx"][j].run()
+        pipe["done"][j].record(pipe["s3"])
+    pipe["coder"][i].finish()
+    cur.wait_stream(s2)
+def pipelined_early():
+    # as pipelined, but the next batch's context indexing is enqueued at the start of the step (beside the binarisation and the
+    # reconstruct kernel) instead of behind the binarisation
+    cur = torch.cuda.current_stream(dev)
+    i = pipe["k"] & 1; j = 1 - i
+    pipe["k"] += 1
+    s2.wait_stream(cur)
+    pipe["s3"].wait_stream(cur)
+    cur.wait_event(pipe["done"][i])
+    with torch.cuda.stream(pipe["s3"]):
+        pipe["ctx"][j].run()
+        pipe["done"][j].record(pipe["s3"])
+    pipe["coder"][i].binarise()
+    with torch.cuda.stream(s2):
+        sess.run()
+    pipe["coder"][i].finish()
+    cur.wait_stream(s2)
 ev_emit = torch.cuda.Event()
 def split_recon_main():
     # as split_coder, but the reconstruct kernel sits right behind the binarisation in the main queue and the coder's second half comes
@@ -82,6 +123,8 @@ def free_running():
         sess.run()
     ctx.run(); coder.run()
 modes = (("one stream", serial), ("two streams", overlapped), ("recon last", recon_last), ("split coder", split_coder), ("split rmain", split_recon_main), ("recon last", recon_last))
+if pipe:
+    modes = (("one stream", serial), ("recon last", recon_last), ("pipelined", pipelined), ("pipe early", pipelined_early), ("pipelined", pipelined), ("pipe early", pipelined_early))
 if halves:
     modes = (("one stream", serial), ("recon last", recon_last), ("halves first", recon_halves), ("halves last", recon_halves_last), ("halves first", recon_halves), ("halves last", recon_halves_last))
 for name, fn in modes:
