@@ -45,6 +45,12 @@ CONFIGS = {
 }
 
 
+# SURVEY 8(d), Config 2 (= BASELINE.json configs[1]): "res/BA_MW_D.264 (... also BANM_MW_D, BA1_Sony_D, BAMQ1/2_JVC_C, BA1_FT_C, SVA_BA1_B/BA2_D,
+# MIDR/NRF/MPS_MW)"
+MIXED_STREAMS = ["BA_MW_D.264", "BANM_MW_D.264", "BA1_Sony_D.jsv", "BAMQ1_JVC_C.264", "BAMQ2_JVC_C.264", "BA1_FT_C.264", "SVA_BA1_B.264",
+                 "SVA_BA2_D.264", "MIDR_MW_D.264", "NRF_MW_E.264", "MPS_MW_A.264"]
+
+
 def spawn_ranks(args):
     """--gpus N without a launcher: N fresh child processes (this one never touches a GPU), rank 0's line is ours"""
     import socket
@@ -172,6 +178,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the host-stage (front end / restore / end-to-end) measurements")
     ap.add_argument("--no-pipeline", action="store_true", help="every batch on its own: no second batch's context indexing beside the coder")
+    ap.add_argument("--mixed", action="store_true", help="configs[1] as a heterogeneous batch: the eleven Baseline streams SURVEY 8(d) lists, interleaved "
+                                                         "(46 of each = 506 streams per GPU), the longest first within every group of eleven")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                                   # does not return
@@ -225,7 +233,12 @@ def main():
             coll_dev = None
             collectives = "gloo (RCCL failed on this node: %s)" % type(e).__name__
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.mixed:
+        assert args.config == 1, "--mixed is configs[1]'s heterogeneous batch"
+        cfg["streams"] = MIXED_STREAMS
+        cfg["n"] = 46 * len(MIXED_STREAMS)
+        cfg["what"] = "configs[1], heterogeneous: " + ", ".join(MIXED_STREAMS) + " interleaved, %d streams per GPU"
     per_gpu = args.streams or cfg["n"]
     n_frames = args.frames or cfg["frames"]
     # ---- the streams of this configuration, through the product's own host front end ------------------------------------------------------
@@ -237,6 +250,10 @@ def main():
         if n_frames:
             frames = frames[:n_frames]
         distinct.append(frames); datas.append(data); mains.append(main_stream)
+    if args.mixed:                                          # the longest stream first within every group (a workgroup = a stream)
+        idx = sorted(range(len(distinct)), key=lambda k: -sum(f.mb_w * f.mb_h for f in distinct[k]))
+        distinct, datas, mains = [distinct[k] for k in idx], [datas[k] for k in idx], [mains[k] for k in idx]
+        cfg["streams"] = [cfg["streams"][k] for k in idx]
     # input bytes a stream stands for: the whole file, or the share of the pictures used
     full = [lh.parse_file(d)[0] for d in datas] if n_frames else distinct
     stream_bytes = [len(d) * sum(f.mb_w * f.mb_h for f in fr) / max(1, sum(f.mb_w * f.mb_h for f in fu)) for d, fr, fu in zip(datas, distinct, full)]
@@ -383,12 +400,20 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes from the
     # committed rocprofv3 --pmc passes over the same launch (profiles/traffic.json), corrected as the guide prescribes
     traffic = coder_traffic = None
+    traffic_note = "no counters committed for this configuration and batch size"
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        t = tj["recon_chain_kernel"]
-        if t["streams"] == n_local and args.config == 1:
-            traffic = (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
-            coder_traffic = sum((2.0 * v["fetch_size_kb"] + v["write_size_kb"]) * 1024.0 for k, v in tj.items() if k.startswith("coder_"))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(str(args.config))
+        if tj is not None and not args.mixed:
+            have = L.lib().lh264_build_id().decode()
+            if tj["streams"] != n_local:
+                traffic_note = "profiles/traffic.json holds the counters of a %d-stream batch, this run has %d" % (tj["streams"], n_local)
+            elif tj["build_id"] != have:
+                traffic_note = "profiles/traffic.json was taken on build %s, this library is build %s: not reported" % (tj["build_id"], have)
+            else:
+                t = tj["kernels"]["recon_chain_kernel"]
+                traffic = (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
+                coder_traffic = sum((2.0 * v.get("fetch_size_kb", 0.0) + v.get("write_size_kb", 0.0)) * 1024.0 for k, v in tj["kernels"].items() if k.startswith("coder_"))
+                traffic_note = "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, %s, build %s" % (tj["source"], have)
     except (OSError, KeyError, ValueError):
         pass
 
@@ -406,19 +431,50 @@ def main():
     # ---- parity outside the timed region ---------------------------------------------------------------------------------------------------
     # every stream's compressed size must be what the reference wrote (fixture: the files of its console application), the last
     # picture of the first and last replica must have the reference decoder's plane CRCs where the fixture has them
-    ref_tagged = []
-    for name in cfg["streams"]:
+    # (a stream used whole: the files of the reference's console application, tests/golden/cli_*.npz; the first pictures of a longer
+    # stream: what the reference wrote after exactly those pictures, tests/golden/bench_cut.json - length and SHA-1 of every tag)
+    import hashlib
+    cuts = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_cut.json")))
+    sweep = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_sweep.json")))
+    ref_tagged, ref_tags = [], []
+    for k, name in enumerate(cfg["streams"]):
         p = os.path.join(ROOT, "tests", "golden", "cli_" + name + ".npz")
-        if os.path.exists(p) and whole[len(ref_tagged)]:
+        cut = cuts.get("%s:%d" % (name, len(distinct[k])))
+        if os.path.exists(p) and whole[k]:
             z = np.load(p)
-            ref_tagged.append(sum(len(z[k]) for k in z.files if k.startswith("tag_")))
+            ref_tags.append({int(f[4:]): (len(z[f]), hashlib.sha1(z[f].tobytes()).hexdigest()) for f in z.files if f.startswith("tag_")})
+        elif whole[k] and name in sweep and sweep[name].get("compress_rc") == 0:
+            # (the sweep of the unmodified reference over every shipped stream, tests/golden/ref_sweep.json: size and SHA-1 of every file)
+            ref_tags.append({int(t): (v[0], v[1]) for t, v in sweep[name]["files"].items() if t.isdigit()})
+        elif cut is not None and cut["pictures"] == len(distinct[k]):
+            ref_tags.append({int(t): (v[0], v[1]) for t, v in cut["tags"].items()})
         else:
-            ref_tagged.append(None)
-    for c in range(n_local):
-        want = ref_tagged[(my_kinds[0] + c) % len(distinct)]
-        assert want is None or int(coded_local[c]) == want, "stream %d: %d coded bytes, the reference wrote %d" % (c, coded_local[c], want)
+            ref_tags.append(None)
+        ref_tagged.append(None if ref_tags[-1] is None else sum(v[0] for v in ref_tags[-1].values()))
+    # every batch that was coded in the timed steps: both sets of buffers when two batches are in flight
+    checked = {"batches": 0, "streams_sizes": 0, "streams_sha1": 0}
+    from losslessh264_amd.coder import TAG_OF_SLOT
+    for cd in coders:
+        ln = cd.d_len.cpu().numpy().reshape(n_local, L.N_TAG_SLOTS + 1)
+        assert not ln[:, L.N_TAG_SLOTS].any(), "device coder status %s" % sorted(set(ln[:, L.N_TAG_SLOTS].tolist()))
+        checked["batches"] += 1
+        for c in range(n_local):
+            want = ref_tags[(my_kinds[0] + c) % len(distinct)]
+            if want is None:
+                continue
+            got = {TAG_OF_SLOT[sl]: int(ln[c, sl]) for sl in range(35) if ln[c, sl]}
+            assert got == {t: v[0] for t, v in want.items() if v[0]}, "stream %d: tag sizes %s, the reference wrote %s" % (c, got, {t: v[0] for t, v in want.items()})
+            checked["streams_sizes"] += 1
+        for k in range(len(distinct)):                  # the bytes of the first and the last replica of every distinct stream
+            if ref_tags[k] is None:
+                continue
+            reps = [i for i in range(n_local) if (my_kinds[0] + i) % len(distinct) == k]
+            for c in sorted({reps[0], reps[-1]}) if reps else []:
+                tg = cd.tags(c)
+                assert {t: hashlib.sha1(b).hexdigest() for t, b in tg.items()} == {t: v[1] for t, v in ref_tags[k].items() if v[0]}, "stream %d: coded bytes differ from the reference's" % c
+                checked["streams_sha1"] += 1
     roundtrip = None
-    if args.config == 1:
+    if args.config == 1 and not args.mixed:
         ref_frames = golden_io.load("bench_BA_MW_D.264")
         for c in (0, n_local - 1):
             got = sess.picture(c, len(order[0]) - 1)
@@ -432,7 +488,7 @@ def main():
         # ratio of what was coded: the tagged streams against the share of the input they stand for (the default stream is per file)
         roundtrip = {"tagged_bytes_per_input_byte": float(coded_local.sum()) / max(1.0, local_bytes),
                      "coded_bytes_equal_reference_files": [w is not None for w in ref_tagged]}
-        if all(w is not None for w in ref_tagged):
+        if all(w is not None for w in ref_tagged) and all(whole):
             # whole streams: size and round trip of one replica of every distinct stream, as for configs[1]
             ok = True
             for k in range(len(distinct)):
@@ -458,7 +514,7 @@ def main():
                 assert len(set(map(tuple, rows[:, 1:].tolist()))) == 1, "replicas of one stream differ between ranks"
 
     host_stages = None
-    if rank == 0 and world == 1 and not args.no_cpu and not args.no_host and args.config == 1:
+    if rank == 0 and world == 1 and not args.no_cpu and not args.no_host and args.config == 1 and not args.mixed:
         # host stages on this box's cores (rows f1 / f2): the front end (parse + default stream + syntax symbols) and the restore
         # direction (adaptive decode + CAVLC writer), one stream per thread, bounded to a few seconds each; and the whole compress
         # direction behind one C call, host bytes in -> host bytes out (parse, staging, PCIe, kernels, download)
@@ -499,6 +555,17 @@ def main():
         total_bytes = local_bytes * world * args.steps        # every rank holds the same mix (weak scaling)
         a18 = k_ms["recon"] + k_ms["ctx"]
         what = cfg["what"] % ((per_gpu,) if args.config == 1 else (len(order[0]), per_gpu))
+        mixed = None
+        if args.mixed:
+            # how much of the launch is the longest stream's own chain: one workgroup (or one (stream, partition) wave) cannot go faster
+            lone = lh.ReconSession([order[0]], device=local_rank)
+            lone.run(); torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); lone.run(); e1.record(); torch.cuda.synchronize(dev)
+            mbs = [sum(f.mb_w * f.mb_h for f in fr) for fr in order]
+            mixed = {"streams": cfg["streams"], "macroblocks_per_stream": mbs, "order": "the longest stream first within every group of %d consecutive workgroups" % len(order),
+                     "recon_chain_kernel_ms_longest_stream_alone": e0.elapsed_time(e1),
+                     "note": "one workgroup per stream: the launch cannot end before its longest stream's chain does; compare with stage_ms.a1_a7_recon_chain_kernel"}
         out = {
             "metric": "MB/s .264 recompressed (bit-exact roundtrip) + ratio, 1/2/4/8 MI355X",
             "value": total_bytes / dt / 1e6, "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -518,12 +585,12 @@ def main():
                        "ms_per_step_one_batch_in_flight": unpipelined_ms,
                        "stage_ms": {"a1_a7_recon_chain_kernel": k_ms["recon"], "a8_ctx_kernels": k_ms["ctx"], "a9_a10_coder_kernels": k_ms["coder"]},
                        "a1_a8_only_MB_per_s": local_bytes / (a18 * 1e-3) / 1e6,
-                       "compression": roundtrip, "host_stages": host_stages,
+                       "compression": roundtrip, "parity_checked": checked, "mixed_batch": mixed, "host_stages": host_stages,
                        "multi_gpu": {"result_records_gathered": n_records, "global_streams": n_global, "collectives": collectives,
                                      "measured_on_hardware": ("rehearsal: all ranks on GPU 0, gloo collectives - not a scaling measurement" if rehearse
                                                               else "this line" if world > 1 else "single GPU; N > 1 unmeasured in this run")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "recon_chain_kernel", "kernel_ms": recon_ms, "kernel_ms_alone": k_ms["recon"], "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": traffic, "traffic_source": traffic_note, "kernel": "recon_chain_kernel", "kernel_ms": recon_ms, "kernel_ms_alone": k_ms["recon"], "algorithmic_bytes_per_launch": alg_bytes,
                          "coder_stage": {"bound": "hbm", "achieved": coder_bytes / (k_ms["coder"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": coder_bytes / (k_ms["coder"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": k_ms["coder"], "algorithmic_bytes": coder_bytes, "traffic": coder_traffic,
                                          "note": "symbols read twice + 8-byte decision words and 2-byte list entries written and read once + output; "

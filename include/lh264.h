@@ -140,6 +140,9 @@ typedef struct lh264_frame_job {
 
 /* ---- library / device management ----------------------------------------- */
 int         lh264_abi_version(void);
+/* identifies the build: a hash of the sources the library was compiled from (set by the build recipe, __graft_entry__.build);
+ * measurements kept beside the sources (profiles/traffic.json) name the build they were taken on */
+const char* lh264_build_id(void);
 const char* lh264_last_error(void);
 /* number of visible HIP devices (<=0: none; every compute entry point then fails loudly) */
 int         lh264_device_count(void);

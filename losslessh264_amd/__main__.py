@@ -24,7 +24,7 @@ def compress_single(src, dst):
     blob = None
     why = ""
     try:
-        frames, err, main = lh.parse_file(data)
+        frames, err, main, pcm = lh.parse_file(data, pcm=True)
         if err:
             why = err
         elif frames:
@@ -34,6 +34,8 @@ def compress_single(src, dst):
             coder.run()
             ctx.synchronize()
             tags = coder.tags(0)
+            if pcm:
+                tags[70] = pcm          # LH264_TAG_PCM: the samples of the I_PCM macroblocks travel as they are
             if lh.restore(main, tags) == data:
                 blob = lh.pack(main, tags)
             else:
@@ -61,7 +63,7 @@ def restore_single(src, dst):
 def compress(src, dst, yuv=None):
     import losslessh264_amd as lh
     data = open(src, "rb").read()
-    frames, err, main = lh.parse_file(data)
+    frames, err, main, pcm = lh.parse_file(data, pcm=True)
     if err:
         raise SystemExit("cannot compress %s: %s" % (src, err))
     ctx = lh.CtxSession([frames])
@@ -70,6 +72,8 @@ def compress(src, dst, yuv=None):
     coder.run()
     ctx.synchronize()
     tags = coder.tags(0)
+    if pcm:
+        tags[70] = pcm                  # LH264_TAG_PCM (the reference writes no such file: its own restore fails on I_PCM streams)
     with open(dst, "wb") as f:
         f.write(main)
     for t, b in tags.items():

@@ -41,6 +41,7 @@ _lib = None
 
 _SIGS = {
     "lh264_abi_version": (C.c_int, []),
+    "lh264_build_id": (C.c_char_p, []),
     "lh264_last_error": (C.c_char_p, []),
     "lh264_device_count": (C.c_int, []),
     "lh264_set_device": (C.c_int, [C.c_int]),

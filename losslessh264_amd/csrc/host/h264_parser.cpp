@@ -548,6 +548,7 @@ struct Parser::Impl {
       if (cur->slice_syn.size() == cur->slices.size()) symbolizer.picture (*cur);
       else { cur->syn_off.assign ((size_t)cur->mb_w * cur->mb_h + 1, 0); cur->syn_syms.clear(); }
     }
+    for (uint8_t c : cur->covered) if (!c) { self->damaged_ = true; break; }
     cur->complete = true;
     self->pictures_done_++;
     if (self->keep_frames_) self->frames_.push_back (std::move (cur));
@@ -889,7 +890,8 @@ bool Parser::Impl::parse_mb_cavlc (BitReader& br, SliceCtx& c, int k, int& qp_pr
       memcpy (y.sub_type, &d->persist_sub[(size_t)k * 4], 4);
       y.delta_qp = (int)m.qp_y - d->slice_cached_qp;
       d->slice_cached_qp = m.qp_y;
-      if (m.mb_type != LH264_MB_IPCM) d->finish_levels (k);
+      // (a destructor: an allocation failure in here must not escape - it would end the process - but fail the stream)
+      try { if (m.mb_type != LH264_MB_IPCM) d->finish_levels (k); } catch (const std::exception& e) { d->fail (std::string ("internal: ") + e.what()); }
     }
   } syn_done = {this, y, m, k};
   uint32_t mbt = br.ue();
@@ -1241,7 +1243,8 @@ bool Parser::Impl::parse_mb_cabac (Cabac& cb, SliceCtx& c, int k, int& qp_prev, 
       memcpy (y.sub_type, &d->persist_sub[(size_t)k * 4], 4);
       y.delta_qp = (int)m.qp_y - d->slice_cached_qp;
       d->slice_cached_qp = m.qp_y;
-      if (m.mb_type != LH264_MB_IPCM) d->finish_levels (k);
+      // (a destructor: an allocation failure in here must not escape - it would end the process - but fail the stream)
+      try { if (m.mb_type != LH264_MB_IPCM) d->finish_levels (k); } catch (const std::exception& e) { d->fail (std::string ("internal: ") + e.what()); }
     }
   } syn_done = {this, y, m, k};
 
@@ -1619,7 +1622,9 @@ int Parser::Impl::handle_nal (const uint8_t* nal, size_t len) {
     cur->slices.push_back (sl);
     if (sh.first_mb < 0 || (uint32_t)sh.first_mb >= (uint32_t) (S.mb_w * S.mb_h)) { fail ("first_mb_in_slice out of range"); return -1; }
     last_hdr_bits = (int)br.pos; last_cabac = P.cabac;
-    if (P.cabac ? !parse_slice_data_cabac (br, c) : !parse_slice_data_cavlc (br, c)) return -1;
+    // (a slice that fails is not modelled: the I_PCM samples it appended so far would shift every later macroblock's in the PCM stream)
+    const size_t pcm_mark = self->pcm_.size();
+    if (P.cabac ? !parse_slice_data_cabac (br, c) : !parse_slice_data_cavlc (br, c)) { self->pcm_.resize (pcm_mark); return -1; }
     return 0;
   }
   if (type == 10 || type == 11) finish_picture();

@@ -258,6 +258,9 @@ class Parser {
   // on: the per-picture arrays come from chunks owned by this parser (see StreamArena)
   void set_stream_arena (bool on) { if (on && !arena_) arena_.reset (new StreamArena()); else if (!on) arena_.reset(); }
   long pictures_done() const { return pictures_done_; }
+  // a completed picture had macroblocks no slice covers (lost slices): the reference conceals them (error_concealment.cpp), which is not
+  // modelled - the recompressed form of such a stream does not restore; callers that promise a round trip store it verbatim
+  bool damaged() const { return damaged_; }
 
  private:
   struct Impl;
@@ -266,7 +269,7 @@ class Parser {
   std::vector<std::unique_ptr<FrameOut>> frames_;
   std::string err_;
   int n_unsupported_ = 0;
-  bool keep_frames_ = true, want_coeffs_ = true, lazy_levels_ = false, sparse_levels_ = false; long pictures_done_ = 0;
+  bool keep_frames_ = true, want_coeffs_ = true, lazy_levels_ = false, sparse_levels_ = false; long pictures_done_ = 0; bool damaged_ = false;
   MainStreamWriter main_;
   std::vector<uint8_t> pcm_;
   friend struct Impl;

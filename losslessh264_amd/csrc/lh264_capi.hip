@@ -21,23 +21,34 @@ __global__ void recon_chain_kernel (const lh264_frame_job_t* jobs, const int32_t
 __global__ void ctx_nnz_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
 __global__ void ctx_inherit_chain_kernel (const lh264_ctx_job_t* jobs, const int32_t* chain_first, int n_chains);
 __global__ void ctx_symbols_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
-__global__ void coder_jobs_kernel (const lh264_code_job_t* jobs, const int32_t* chain_first, int n_jobs, int n_chains, uint32_t* seg0, uint32_t* job_chain, uint32_t* chain_info);
-__global__ void coder_count_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, int n_jobs, uint32_t* seg_cnt);
-__global__ void coder_scan_kernel (const uint32_t* seg0, const int32_t* chain_first, const uint32_t* seg_cnt, uint32_t* seg_doff, uint32_t* chain_info, int n_chains);
+__global__ void coder_jobs_kernel (const lh264_code_job_t* jobs, const int32_t* chain_first, int n_jobs, int n_chains, unsigned seg_bound, uint32_t* seg0, uint32_t* seg_job, uint32_t* job_chain, uint32_t* chain_info);
+__global__ void coder_count_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* seg_job, int n_jobs, int log2p, uint32_t* seg_cnt, uint32_t* seg_part);
+__global__ void coder_scan_kernel (const uint32_t* seg0, const int32_t* chain_first, uint32_t* seg_cnt, uint32_t* seg_doff, uint32_t* chain_info, int n_chains);
 __global__ void coder_bases_kernel (uint32_t* chain_info, int n_chains, unsigned long long* totals);
-__global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* job_chain, int n_jobs,
-                                   const uint32_t* seg_doff, const uint32_t* chain_info, uint64_t* D);
-__global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint64_t* D, uint16_t* Q, int n_chains);
-__global__ void coder_chunkmap_kernel (const uint32_t* chain_info, int n_pairs, uint32_t* pair_chunk0);
-__global__ void coder_range_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, int n_chains, int groups,
-                                    uint32_t* chunk_rec, uint32_t* pair_bits);
-__global__ void coder_accum_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, int n_pairs, const uint32_t* chunk_rec,
-                                    const uint32_t* pair_bits, uint32_t* acc);
+__global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* seg_job, const uint32_t* job_chain, int n_jobs, int log2p,
+                                   const uint32_t* seg_doff, const uint32_t* seg_cnt, const uint32_t* seg_part, const uint32_t* chain_info, uint64_t* D);
+__global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint32_t* seg0, const int32_t* chain_first,
+                                      const uint32_t* seg_doff, const uint32_t* seg_part, const uint64_t* D, uint16_t* Q, int n_chains, int log2p);
+__global__ void coder_chunkmap_kernel (const uint32_t* chain_info, int n_pairs, uint32_t* pair_chunk0, uint32_t* pair_coarse0);
+__global__ void coder_range_seed_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_coarse0, int n_pairs, uint32_t* cand);
+__global__ void coder_range_walk1_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs,
+                                          const uint32_t* cand, uint8_t* cand_end, uint32_t* chunk_rec, uint32_t* coarse_bits);
+__global__ void coder_range_cand_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs,
+                                         const uint32_t* cand, uint8_t* cand_end);
+__global__ void coder_range_link_kernel (const uint32_t* pair_coarse0, int n_pairs, const uint32_t* cand, const uint8_t* cand_end, uint32_t* seed, uint32_t* chain_info);
+__global__ void coder_range_walk_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs,
+                                         const uint32_t* cand, const uint32_t* seed, uint32_t* chunk_rec, uint32_t* coarse_bits);
+__global__ void coder_range_scan_kernel (const uint32_t* pair_coarse0, int n_pairs, uint32_t* coarse_bits, uint32_t* pair_bits);
+__global__ void coder_accum_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs,
+                                    const uint32_t* chunk_rec, const uint32_t* coarse_bits, const uint32_t* pair_bits, uint32_t* acc);
 __global__ void coder_bytes_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_bits,
                                     const uint32_t* acc, int n_pairs);
 __global__ void coder_status_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, int n_chains);
 size_t wave_lds_bytes();
 size_t wg_lds_bytes();
+#ifdef LH264_CODER_DEBUG
+void read_rs_stamps (unsigned long long* out, bool reset);
+#endif
 #ifdef LH264_STAMP
 void read_stamps (unsigned long long* out, bool reset);
 #endif
@@ -56,6 +67,10 @@ static int fail (int code, const char* what, hipError_t e = hipSuccess) {
 extern "C" {
 
 int lh264_abi_version (void) { return LH264_ABI_VERSION; }
+#ifndef LH264_BUILD_ID
+#define LH264_BUILD_ID "unknown"
+#endif
+const char* lh264_build_id (void) { return LH264_BUILD_ID; }
 const char* lh264_last_error (void) { return g_err.c_str(); }
 
 int lh264_device_count (void) {
@@ -180,11 +195,27 @@ int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chai
   return LH264_OK;
 }
 
-// Work memory of the coder stages, kept between calls and grown on demand (one set per device; a call holds the device's lock, so
-// two host threads driving the same device take turns).
+// Work memory of the coder stages, kept between calls and grown on demand: one set per device.  The lock only serialises the host
+// side (the enqueue); on the device the calls are ordered by an event: every coder call records `done` on its stream when it has
+// enqueued its last kernel, and a call on ANOTHER stream first makes its stream wait for it - the decision words, tag lists and sums
+// of the previous call are still being read until then.  (Calls on one stream are ordered by the stream.)
 namespace {
 struct CoderWs {
   std::mutex mu;
+  hipEvent_t done = nullptr; hipStream_t last_stream = nullptr; bool busy = false;
+  // before the first kernel of a coder call on `st`
+  int enter (hipStream_t st) {
+    if (busy && st != last_stream) { hipError_t e = hipStreamWaitEvent (st, done, 0); if (e != hipSuccess) return (int)e; }
+    return 0;
+  }
+  // behind its last kernel
+  int leave (hipStream_t st) {
+    if (!done) { hipError_t e = hipEventCreateWithFlags (&done, hipEventDisableTiming); if (e != hipSuccess) return (int)e; }
+    hipError_t e = hipEventRecord (done, st);
+    if (e != hipSuccess) return (int)e;
+    last_stream = st; busy = true;
+    return 0;
+  }
   void* small = nullptr; size_t small_cap = 0;     // job / macroblock / stream tables
   void* big = nullptr; size_t big_cap = 0;         // decision words + tag lists
   unsigned long long* totals_host = nullptr;       // page-locked, 2 x u64
@@ -193,6 +224,9 @@ struct CoderWs {
   int ready_chains = -1, n_pairs = 0; size_t chunk_bound = 0; const lh264_code_stream_t* ready_streams = nullptr;
   uint32_t* info = nullptr; uint64_t* D = nullptr; uint16_t* Q = nullptr;
   uint32_t* pair_chunk0 = nullptr; uint32_t* pair_bits = nullptr; uint32_t* chunk_rec = nullptr; uint32_t* acc = nullptr;
+  uint32_t* pair_coarse0 = nullptr; uint32_t* seed = nullptr; uint32_t* coarse_bits = nullptr; size_t coarse_bound = 0; int n_pairs_last = 0;
+  uint32_t* cand = nullptr; uint8_t* cand_end = nullptr;
+  const uint32_t* seg0 = nullptr; const uint32_t* seg_doff = nullptr; const uint32_t* seg_part = nullptr; const int32_t* chain_first = nullptr; int log2p = 3;
 };
 CoderWs g_coder_ws[16];
 int grow (void** p, size_t* cap, size_t need) {
@@ -212,20 +246,32 @@ size_t up256 (size_t v) { return (v + 255) & ~ (size_t)255; }
 static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
                           int n_chains, int n_jobs, long long total_mbs, hipStream_t st) {
   W.ready_chains = -1;
+  if (W.enter (st)) return fail (LH264_E_HIP, "hipStreamWaitEvent (coder work memory)");
   if (!W.totals_host) HIPCHK (hipHostMalloc ((void**)&W.totals_host, 2 * sizeof (unsigned long long), hipHostMallocDefault));
+  // the partitions of a stream's DynProbs (each resolved by a wave of its own): enough of them to fill the machine with waves
+  // (as few as fill the machine with waves: a partition's runs of decision words get shorter with their number, and a run costs its
+  // wave a look at the segment tables; LH264_CODER_LOG2P overrides, for experiments)
+  int log2p = 3;
+  while (log2p < LH264_CODER_MAX_LOG2P && ((long long)n_chains << log2p) < 8192) log2p++;
+  if (const char* e = getenv ("LH264_CODER_LOG2P")) { const int v = atoi (e); if (v >= 0 && v <= LH264_CODER_MAX_LOG2P) log2p = v; }
+  W.log2p = log2p;
+  const size_t pstride = ((size_t)1 << log2p) + 1;
   // small tables.  A picture of n macroblocks is cut into ceil (n / LH264_CODER_SEG_MBS) segments
   const size_t seg_bound = (size_t)total_mbs / LH264_CODER_SEG_MBS + (size_t)n_jobs + 1;
   const size_t o_seg0 = 0, o_jobchain = up256 ((size_t) (n_jobs + 1) * 4), o_info = o_jobchain + up256 ((size_t) (n_jobs + 1) * 4),
                o_totals = o_info + up256 ((size_t)n_chains * LH264_CODER_INFO_WORDS * 4), o_doff = o_totals + 256,
-               o_cnt = o_doff + up256 (seg_bound * 4 + 4), small_need = o_cnt + up256 (seg_bound * LH264_CODER_CNT_STRIDE * 4 + 4);
+               o_sjob = o_doff + up256 (seg_bound * 4 + 4), o_cnt = o_sjob + up256 (seg_bound * 4 + 4), o_part = o_cnt + up256 (seg_bound * LH264_CODER_CNT_STRIDE * 4 + 4),
+               small_need = o_part + up256 (seg_bound * pstride * 4 + 4);
   if (int rc = grow (&W.small, &W.small_cap, small_need)) return rc;
   uint8_t* sm = (uint8_t*)W.small;
   uint32_t* seg0 = (uint32_t*) (sm + o_seg0); uint32_t* job_chain = (uint32_t*) (sm + o_jobchain); uint32_t* info = (uint32_t*) (sm + o_info);
   unsigned long long* totals = (unsigned long long*) (sm + o_totals); uint32_t* seg_doff = (uint32_t*) (sm + o_doff); uint32_t* seg_cnt = (uint32_t*) (sm + o_cnt);
-  hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, seg0, job_chain, info);
+  uint32_t* seg_part = (uint32_t*) (sm + o_part); uint32_t* seg_job = (uint32_t*) (sm + o_sjob);
+  hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, (unsigned)seg_bound, seg0, seg_job, job_chain, info);
   HIPCHK (hipGetLastError());
+  const unsigned seg_blocks = (unsigned) ((seg_bound + 3) / 4);
   if (n_jobs > 0 && total_mbs > 0) {
-    hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, n_jobs, seg_cnt);
+    hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, n_jobs, log2p, seg_cnt, seg_part);
     HIPCHK (hipGetLastError());
   }
   hipLaunchKernelGGL (lh264::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_cnt, seg_doff, info, n_chains);
@@ -242,21 +288,30 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   if (n_pairs >= (1 << 24)) return fail (LH264_E_ARG, "too many streams in one call");
   const size_t chunk_bound = (size_t)n_q / LH264_CODER_CODE_CHUNK + 2 * (size_t)n_pairs + 1;
   const size_t n_acc = (size_t)n_q + 48 * (size_t)n_pairs + 64;
+  // coarse chunks of the range walk (LH264_CODER_CODE_COARSE decisions): per pair the first one; per chunk its candidate start states (8
+  // bytes; + 4 more words in diagnostic builds), where a walk from each ends, its true start state, the bits it shifts out
+  const size_t coarse_bound = (size_t)n_q / LH264_CODER_CODE_COARSE + 2 * (size_t)n_pairs + 1;
   const size_t o_q = up256 ((size_t)n_words * 8 + 512), o_pc0 = o_q + up256 ((size_t)n_q * 2 + 256), o_pbits = o_pc0 + up256 ((size_t) (n_pairs + 1) * 4),
-               o_crec = o_pbits + up256 ((size_t)n_pairs * 4), o_acc = o_crec + up256 (chunk_bound * 8);
+               o_crec = o_pbits + up256 ((size_t)n_pairs * 4), o_pco0 = o_crec + up256 (chunk_bound * 8), o_seed = o_pco0 + up256 ((size_t) (n_pairs + 1) * 4),
+               o_cand = o_seed + up256 (coarse_bound * 4), o_cend = o_cand + up256 (coarse_bound * 12), o_cbits = o_cend + up256 (coarse_bound * 8),
+               o_acc = o_cbits + up256 (coarse_bound * 4 + 4);
   if (int rc = grow (&W.big, &W.big_cap, o_acc + n_acc * 4 + 256)) return rc;
   uint8_t* bg = (uint8_t*)W.big;
   uint64_t* D = (uint64_t*)bg; uint16_t* Q = (uint16_t*) (bg + o_q);
   uint32_t* pair_chunk0 = (uint32_t*) (bg + o_pc0); uint32_t* pair_bits = (uint32_t*) (bg + o_pbits);
   uint32_t* chunk_rec = (uint32_t*) (bg + o_crec); uint32_t* acc = (uint32_t*) (bg + o_acc);
+  W.pair_coarse0 = (uint32_t*) (bg + o_pco0); W.seed = (uint32_t*) (bg + o_seed); W.coarse_bits = (uint32_t*) (bg + o_cbits); W.coarse_bound = coarse_bound; W.n_pairs_last = n_pairs;
+  W.cand = (uint32_t*) (bg + o_cand); W.cand_end = (uint8_t*) (bg + o_cend);
+  W.seg0 = seg0; W.seg_doff = seg_doff; W.seg_part = seg_part; W.chain_first = chain_first_dev;
   HIPCHK (hipMemsetAsync (acc, 0, n_acc * 4, st));
   if (n_jobs > 0 && total_mbs > 0) {
-    hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, job_chain, n_jobs, seg_doff, info, D);
+    hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, job_chain, n_jobs, log2p, seg_doff, seg_cnt, seg_part, info, D);
     HIPCHK (hipGetLastError());
   }
   W.info = info; W.D = D; W.Q = Q; W.pair_chunk0 = pair_chunk0; W.pair_bits = pair_bits; W.chunk_rec = chunk_rec; W.acc = acc;
   W.chunk_bound = chunk_bound; W.n_pairs = n_pairs; W.ready_chains = n_chains; W.ready_streams = streams_dev;
   W.last_words = n_words; W.last_q = n_q;
+  if (W.leave (st)) return fail (LH264_E_HIP, "hipEventRecord (coder work memory)");
   return LH264_OK;
 }
 
@@ -266,20 +321,36 @@ static int code_finish (CoderWs& W, const lh264_code_stream_t* streams_dev, int 
   uint32_t* chunk_rec = W.chunk_rec; uint32_t* acc = W.acc;
   const size_t chunk_bound = W.chunk_bound; const int n_pairs = W.n_pairs;
   W.ready_chains = -1;
-  hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 (n_chains), dim3 (LH264_CODER_RESOLVE_THREADS), 0, st, streams_dev, info, D, Q, n_chains);
+  if (W.enter (st)) return fail (LH264_E_HIP, "hipStreamWaitEvent (coder work memory)");
+  hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 ((unsigned) ((((size_t)n_chains << W.log2p) + 3) / 4)), dim3 (256), 0, st, streams_dev, info, W.seg0, W.chain_first,
+                      W.seg_doff, W.seg_part, D, Q, n_chains, W.log2p);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_status_kernel, dim3 ((n_chains + 255) / 256), dim3 (256), 0, st, streams_dev, info, n_chains);
   HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_chunkmap_kernel, dim3 (1), dim3 (1024), 0, st, info, n_pairs, pair_chunk0);
+  hipLaunchKernelGGL (lh264::coder_chunkmap_kernel, dim3 (1), dim3 (1024), 0, st, info, n_pairs, pair_chunk0, W.pair_coarse0);
   HIPCHK (hipGetLastError());
-  const int groups = (n_chains + 63) / 64;
-  hipLaunchKernelGGL (lh264::coder_range_kernel, dim3 ((unsigned)groups * 35), dim3 (64), 0, st, info, Q, pair_chunk0, n_chains, groups, chunk_rec, pair_bits);
+  // the bool coders' range recurrence in coarse chunks: start states by lookback, the walk, the running sum of the bits
+  hipLaunchKernelGGL (lh264::coder_range_seed_kernel, dim3 ((unsigned) ((W.coarse_bound + 3) / 4)), dim3 (256), 0, st, info, Q, W.pair_coarse0, n_pairs, W.cand);
   HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_accum_kernel, dim3 ((unsigned) ((chunk_bound + 255) / 256)), dim3 (256), 0, st, info, Q, pair_chunk0, n_pairs, chunk_rec, pair_bits, acc);
+  hipLaunchKernelGGL (lh264::coder_range_walk1_kernel, dim3 ((unsigned) ((W.coarse_bound + 63) / 64)), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs,
+                      W.cand, W.cand_end, chunk_rec, W.coarse_bits);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_range_cand_kernel, dim3 ((unsigned) ((W.coarse_bound + 7) / 8)), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs, W.cand, W.cand_end);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_range_link_kernel, dim3 ((unsigned) ((n_pairs + 63) / 64)), dim3 (64), 0, st, W.pair_coarse0, n_pairs, W.cand, W.cand_end, W.seed, info);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_range_walk_kernel, dim3 ((unsigned) ((W.coarse_bound + 63) / 64)), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs,
+                      W.cand, W.seed, chunk_rec, W.coarse_bits);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_range_scan_kernel, dim3 ((unsigned) ((n_pairs + 3) / 4)), dim3 (256), 0, st, W.pair_coarse0, n_pairs, W.coarse_bits, pair_bits);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_accum_kernel, dim3 ((unsigned) ((chunk_bound + 255) / 256)), dim3 (256), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs,
+                      chunk_rec, W.coarse_bits, pair_bits, acc);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_bytes_kernel, dim3 ((unsigned) ((n_pairs + 63) / 64)), dim3 (64), 0, st, streams_dev, info, Q, pair_bits, acc, n_pairs);
   HIPCHK (hipGetLastError());
   // tag slots 35 .. LH264_N_TAG_SLOTS-1 do not exist: their lengths read 0
+  if (W.leave (st)) return fail (LH264_E_HIP, "hipEventRecord (coder work memory)");
   return LH264_OK;
 }
 
@@ -497,6 +568,21 @@ const lh264_ctx_sym_t* lh264_parser_frame_syn_symbols (const lh264_parser_t* p, 
 const uint32_t* lh264_parser_frame_syn_offsets (const lh264_parser_t* p, int idx) { auto f = pf (p, idx); return f ? f->syn_off.data() : nullptr; }
 const char* lh264_parser_error (const lh264_parser_t* p) { return p ? const_cast<lh264_parser_t*> (p)->p.error().c_str() : ""; }
 
+#ifdef LH264_CODER_DEBUG
+void lh264_debug_read_rs_stamps (unsigned long long* out16, int reset) { lh264::read_rs_stamps (out16, reset != 0); }
+#endif
+#ifdef LH264_RANGE_PROBE
+// diagnostic builds only: the seed words of the last coder call on the current device
+long long lh264_debug_coder_seeds (uint32_t* out, long long cap) {
+  int dev = 0; (void)hipGetDevice (&dev);
+  CoderWs& W = g_coder_ws[dev];
+  uint32_t total = 0;                   // coarse chunks of the call: the probe words lie behind the seeds
+  if (hipMemcpy (&total, W.pair_coarse0 + W.n_pairs_last, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const long long n = (long long)total < cap ? (long long)total : cap;
+  if (hipMemcpy (out, W.cand + 2 * (size_t)total, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
+}
+#endif
 #ifdef LH264_STAMP
 // diagnostic builds only (not declared in lh264.h)
 void lh264_debug_read_stamps (unsigned long long* out16, int reset) { lh264::read_stamps (out16, reset != 0); }

@@ -3,11 +3,16 @@
 #define LH264_CODER_INTERNAL_H_
 #include "../../include/lh264.h"
 
-// the parallel binarisation works on segments of at most this many consecutive macroblocks of a picture (<= 256: one thread each)
-#define LH264_CODER_SEG_MBS 128
+// the parallel binarisation works on segments of at most this many consecutive macroblocks of a picture, one wave each (<= 32: the wave
+// lays a segment out with a lane per macroblock and 16-bit counters per lane)
+#define LH264_CODER_SEG_MBS 32
 // per-segment decision counts (32-bit): [0 .. LH264_N_TAG_SLOTS-1] per tag slot (bit 31: the segment brings the tag's stream into
 // existence), [LH264_N_TAG_SLOTS] all decisions of the segment
 #define LH264_CODER_CNT_STRIDE (LH264_N_TAG_SLOTS + 1)
+// the DynProbs of a stream are cut into P = 2^log2p partitions by a hash of their cell's key; per segment P + 1 words say where each
+// partition's run of decision words starts inside the segment's words
+#define LH264_CODER_MAX_LOG2P 7
+#define LH264_CODER_MAX_PARTS (1 << LH264_CODER_MAX_LOG2P)
 
 // per-stream record (32-bit words)
 #define LH264_CODER_INFO_TAGBASE 0                                   /* [slot] first entry of the tag's list inside the stream's lists */
@@ -29,6 +34,12 @@
 // the bool coder's output is summed up by chunks of this many decisions of a tag's list (a multiple of 8)
 #ifndef LH264_CODER_CODE_CHUNK
 #define LH264_CODER_CODE_CHUNK 256
+#endif
+
+// the range recurrence of a tag's list is walked in coarse chunks of this many decisions (a multiple of LH264_CODER_CODE_CHUNK), each
+// from a start state found by looking back over the decisions in front of it (coder_range_seed_kernel)
+#ifndef LH264_CODER_CODE_COARSE
+#define LH264_CODER_CODE_COARSE 16384
 #endif
 
 // status bits reported in out_len_dev[LH264_N_TAG_SLOTS]

@@ -232,73 +232,145 @@ __device__ __forceinline__ SymCount sym_count (uint32_t prior, int value, int ki
   return c;
 }
 
-// a decision word (64 bits): the low dword is the key of the prior's cell (LH264_PRIOR form; 0 for a raw bit), the high dword
-// bits 0..3 the place in the cell, bit 4 the bit, bits 5..10 the tag slot, bit 31 "raw bit" (coded with TEST_PROB)
-struct EmitSink {
-  GLB uint64_t* D; uint32_t pos, key;
-  __device__ __forceinline__ void touch (int) {}
-  __device__ __forceinline__ void cell (uint32_t k) { key = k; }
-  __device__ __forceinline__ void dec (int j, int bit, int tag) {
-    const uint32_t t = (uint32_t)tag_slot (tag) << 5 | (uint32_t) (bit & 1) << 4;
-    const bool raw = (j & 0xff) == 0xff;
-    D[pos++] = raw ? (uint64_t) (0x80000000u | t) << 32 : ((uint64_t) (t | (uint32_t) (j & 15)) << 32 | key);
+// ---- decision j of a symbol in closed form (the same cases as binarize / sym_count above, without walking the binarisation) ----
+// The parallel binarisation works a lane per DECISION: the j-th decision of a symbol follows from kind, value and j alone.
+// key: the cell of the DynProb (LH264_PRIOR form), place: its place in the cell; raw bits (coded with the shared TEST_PROB,
+// compression_stream.h:363,441-448) carry CODER_RAW_KEY, place 0.
+#define CODER_RAW_KEY 0xf8000000u
+struct Decision { uint32_t key; int place, bit, tag; };
+// place of mantissa decision i in emitInt's binary search over 4 mantissa priors (:559-571), given the two bits before it; -1: raw
+__device__ __forceinline__ int man_place (int i, int b0, int b1) { return i == 0 ? 2 : i == 1 ? (b0 ? 3 : 1) : (i == 2 && !b0 && !b1) ? 0 : -1; }
+// emitInt behind its zero flag and sign: decision j of data >= 1 - unary exponent on ebase.. (E places), then mantissa on mbase..
+__device__ __forceinline__ void int_tail_at (Decision& d, int j, int data, int order, int ebase, int E, int mbase, int tag_exp, int tag_man) {
+  const int a = data - 1, high = 1 + (a >> order), l2 = 31 - __clz (high);
+  if (j <= l2) { d.place = ebase + min (j, E - 1); d.bit = j < l2; d.tag = tag_exp; return; }
+  const int i = j - l2 - 1;
+  auto mbit = [&] (int k) -> int { return k < l2 ? (high >> (l2 - 1 - k)) & 1 : (a >> ((order - 1 - (k - l2)) & 31)) & 1; };     // (k beyond the mantissa: unused)
+  const int pl = man_place (i, mbit (0), mbit (1));
+  d.bit = mbit (i); d.tag = tag_man;
+  if (pl < 0) { d.key = CODER_RAW_KEY; d.place = 0; } else d.place = mbase + pl;
+}
+// emitUEGkInt (:575-591): zero 0, sign 1, unary on 2..5 up to N ones, escape = emitInt (zero at 6, exponent 7.., mantissa 7+E..)
+__device__ __forceinline__ void uegk_at (Decision& d, int j, int value, int N, int E, int order, int tag_exp, int tag_man, int tag_zero, int tag_sign) {
+  if (j == 0) { d.place = 0; d.bit = value == 0; d.tag = tag_zero; return; }
+  if (j == 1) { d.place = 1; d.bit = value < 0; d.tag = tag_sign; return; }
+  const int u = (value < 0 ? -value : value) - 1, nu = u >= N ? N : u + 1;
+  int i = j - 2;
+  if (i < nu) { d.place = 2 + min (i, 3); d.bit = i < u; d.tag = tag_man; return; }
+  i -= nu;                                                    // the escape: u >= N
+  if (i == 0) { d.place = 6; d.bit = u - N == 0; d.tag = tag_zero; return; }
+  int_tail_at (d, i - 1, u - N, order, 7, E, 7 + E, tag_exp, tag_man);
+}
+// Branch<nbits> (:117-166): node offset after the first j bits = one per zero bit + the subtree sizes skipped by the one bits
+__device__ __forceinline__ void tree_at (Decision& d, uint32_t prior, int groups, unsigned off0, unsigned data, int nbits, int j) {
+  data &= (1u << nbits) - 1u;
+  const unsigned top = j ? data >> (nbits - j) : 0u;
+  const unsigned off = off0 + (unsigned)j - (unsigned)__popc (top) + (top << (nbits - j));
+  d.key = (prior & 0xf8000000u) | ((prior & 0x7ffffffu) * (uint32_t)groups + (off >> 4));
+  d.place = (int) (off & 15u);
+  d.bit = (int) ((data >> (nbits - 1 - j)) & 1u);
+}
+__device__ __forceinline__ Decision decision_at (uint32_t prior, int value, int kind, int pad, int j) {
+  enum { T_LDC = 17, T_CRDC = 18, T_LAC_0_EOB = 19, T_LAC_N_EOB = 24, T_CRAC_EOB = 29 };
+  Decision d; d.key = prior; d.place = 0; d.bit = 0; d.tag = pad;
+  const int table = (int) (prior >> 27);
+  switch (kind) {
+  case LH264_SYM_LUMA_DC: case LH264_SYM_CHROMA_DC: case LH264_SYM_NZ4: case LH264_SYM_NZ8: {      // IntPrior<3,4> / UnsignedIntPrior<3,4>
+    const bool dc = kind == LH264_SYM_LUMA_DC || kind == LH264_SYM_CHROMA_DC;
+    d.tag = kind == LH264_SYM_LUMA_DC ? T_LDC : kind == LH264_SYM_CHROMA_DC ? T_CRDC : (((prior / 27u) % 3u) ? T_CRAC_EOB : T_LAC_0_EOB);
+    d.key = LH264_PRIOR (kind == LH264_SYM_LUMA_DC ? LH264_TB_LDC : kind == LH264_SYM_CHROMA_DC ? LH264_TB_CDC : kind == LH264_SYM_NZ4 ? LH264_TB_NZ4 : LH264_TB_NZ8, prior);
+    if (j == 0) { d.place = 7; d.bit = value == 0; break; }
+    if (dc && j == 1) { d.place = 8; d.bit = value > 0; break; }
+    int_tail_at (d, j - (dc ? 2 : 1), value < 0 ? -value : value, 0, 0, 3, 3, d.tag, d.tag);
+    break; }
+  case LH264_SYM_AC4: case LH264_SYM_AC8: {                 // UEGkIntPrior<14,4,2,4,0>; tags by colour / first scan position (encode4x4)
+    const uint32_t nco = kind == LH264_SYM_AC4 ? 16u : 64u;
+    const uint32_t outer = prior / 3125u;
+    const int emitted = (int) (outer % nco), color = (int) ((outer / nco) % 3u), code = (int) ((outer / nco / 3u) % 16u);
+    const int first = color == 0 && emitted == 0 && code != 1;
+    const int base = color ? T_CRAC_EOB : (first ? T_LAC_0_EOB : T_LAC_N_EOB);
+    d.key = LH264_PRIOR (kind == LH264_SYM_AC4 ? LH264_TB_AC4 : LH264_TB_AC8, prior);
+    uegk_at (d, j, value, 14, 2, 0, base + 2, base + 3, base + 1, base + 4);
+    break; }
+  case LH264_SYM_BIT: d.bit = value != 0; break;
+  case LH264_SYM_RAW: d.key = CODER_RAW_KEY; d.bit = (value >> ((int)prior - 1 - j)) & 1; break;
+  case LH264_SYM_MVD: uegk_at (d, j, value, 9, 3, 3, pad, pad, pad, pad); break;      // UEGkIntPrior<9,4,3,4,3>
+  case LH264_SYM_TREE: {
+    int nbits = 4, groups = 1;
+    if (table == LH264_TB_SKIPRUN) { nbits = 9; groups = 32; } else if (table == LH264_TB_SUBMB) { nbits = 8; groups = 16; }
+    else if (table == LH264_TB_CBPC) nbits = 2;
+    tree_at (d, prior, groups, 0u, (unsigned) (uint16_t)value, nbits, j);
+    break; }
+  case LH264_SYM_POW2: {                                    // emitBitsZeroToPow2Inclusive<nbits>: priors[0], then the tree in priors[1..]
+    const bool qpl = table == LH264_TB_QPL;
+    const int groups = qpl ? 8 : 1;
+    const unsigned preferred = qpl ? 0u : (prior & 0x7ffffffu), data = (unsigned) (uint16_t)value;
+    if (j == 0) { d.key = (prior & 0xf8000000u) | ((prior & 0x7ffffffu) * (uint32_t)groups); d.bit = data != preferred; break; }
+    tree_at (d, prior, groups, 1u, data > preferred ? data - 1u : data, qpl ? 7 : 3, j - 1);
+    break; }
+  default: break;
   }
-};
+  d.tag = tag_slot (d.tag);
+  return d;
+}
+// which of the stream's P partitions (a power of two) the DynProbs of a cell belong to: every partition is resolved by a wave of its own
+__device__ __forceinline__ uint32_t cell_part (uint32_t key, int log2p) { return log2p ? ((key ^ (key >> 15)) * 0x2C1B3C6Du) >> (32 - log2p) : 0u; }
+
+// a decision word (64 bits), as the binarisation leaves it for the resolve kernel: bits 0..31 the key of the DynProb's cell (LH264_PRIOR
+// form; CODER_RAW_KEY: the shared TEST_PROB), 32..35 the place in the cell, 36 the bit, 37..63 the entry of the stream's tag lists the
+// decision becomes (a stream's lists hold fewer than 2^27 entries per call; coder_scan_kernel checks it)
+#define CODER_QPOS_BITS 27
+
+// order LDS traffic between the lanes of one wave: the DS instructions of a wave execute in issue order, so all that is needed is to
+// keep the COMPILER from moving memory operations across this point
+__device__ __forceinline__ void wsync() { asm volatile ("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile ("" ::: "memory"); }
 
 // ---- segments: the unit of the parallel binarisation -----------------------------------------------------------------------------
-// A segment = up to CODER_SEG consecutive macroblocks of one picture.  Its symbols in coding order are, macroblock after macroblock,
-// the host list with the coefficient symbols in place of the marker; the workgroup of a segment lays that order out once in LDS
-// (where each macroblock's symbols start, where its marker is) and then walks the symbols 64 per wave step whatever macroblock they
-// belong to - a wave per macroblock would idle most lanes on the many macroblocks with a handful of symbols.
+// A segment = up to CODER_SEG consecutive macroblocks of one picture, worked on by ONE wave (a workgroup = four segments; no
+// workgroup barrier anywhere).  Its symbols in coding order are, macroblock after macroblock, the host list with the coefficient
+// symbols in place of the marker; the wave lays that order out once in LDS (where each macroblock's symbols start, where its marker is).
 #define CODER_SEG LH264_CODER_SEG_MBS
 struct SegLds {
   uint32_t hoff[CODER_SEG + 1];      // host symbols of macroblock k start here (offsets into the picture's list)
   uint32_t sbase[CODER_SEG + 1];     // symbols of the segment before macroblock k, in coding order
   uint16_t mc[CODER_SEG];            // coefficient symbols of macroblock k
   uint16_t p[CODER_SEG];             // position of the marker in macroblock k's host list (0xffff: none)
-  uint32_t wsum[4];
-  uint32_t cnt[4][LH264_N_TAG_SLOTS + 2];      // per wave (the symbols of a step mostly count towards the same few tags)
 };
 struct Seg { const lh264_code_job_t* J; int job, k0, n; uint32_t total; };
-// which picture and which macroblocks block `b` works on: seg0[] = segments before picture j
-__device__ __forceinline__ bool seg_locate (const lh264_code_job_t* jobs, const uint32_t* seg0, int n_jobs, uint32_t b, Seg& S) {
+// which picture and which macroblocks segment `b` is: seg0[] = segments before picture j, seg_job[] = the picture of every segment
+__device__ __forceinline__ bool seg_locate (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* seg_job, int n_jobs, uint32_t b, Seg& S) {
   if (b >= seg0[n_jobs]) return false;
-  uint32_t lo = 0, hi = (uint32_t)n_jobs;              // largest j with seg0[j] <= b
-  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (seg0[mid] <= b) lo = mid; else hi = mid; }
-  S.job = (int)lo; S.J = jobs + lo;
-  S.k0 = (int) (b - seg0[lo]) * CODER_SEG;
+  const uint32_t j = seg_job[b];
+  S.job = (int)j; S.J = jobs + j;
+  S.k0 = (int) (b - seg0[j]) * CODER_SEG;
   S.n = min (CODER_SEG, S.J->n_mbs - S.k0);
   return S.n > 0;
 }
-// lay the segment out (all 256 threads); afterwards L.sbase[S.n] = S.total symbols
-__device__ __forceinline__ void seg_layout (LDS SegLds& L, Seg& S, int tid) {
+// lay the segment out (one wave); afterwards L.sbase[S.n] = S.total symbols
+__device__ __forceinline__ void seg_layout (LDS SegLds& L, Seg& S, int lane) {
   const GLB uint32_t* off = glb<const uint32_t> (S.J->syn_off_dev) + S.k0;
   const GLB uint16_t* cn = glb<const uint16_t> (S.J->ctx_n_syms_dev) + S.k0;
-  if (tid <= S.n) L.hoff[tid] = off[tid];
-  if (tid < S.n) { L.mc[tid] = cn[tid]; L.p[tid] = 0xffffu; }
-  __syncthreads();
+  if (lane <= S.n) L.hoff[lane] = off[lane];
+  if (lane < S.n) { L.mc[lane] = cn[lane]; L.p[lane] = 0xffffu; }
+  wsync();
   // the markers: every host symbol of the segment is looked at once
   const GLB uint64_t* hs = glb<const uint64_t> (S.J->syn_syms_dev);
   const uint32_t h0 = L.hoff[0], h1 = L.hoff[S.n];
-  for (uint32_t h = h0 + (uint32_t)tid; h < h1; h += 256u) {
+  for (uint32_t h = h0 + (uint32_t)lane; h < h1; h += 64u) {
     if (((hs[h] >> 48) & 0xffull) == (unsigned long long)LH264_SYM_SPLICE) {
       uint32_t lo = 0, hi = (uint32_t)S.n;               // the macroblock whose list holds position h
       while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (L.hoff[mid] <= h) lo = mid; else hi = mid; }
       L.p[lo] = (uint16_t) (h - L.hoff[lo]);
     }
   }
-  __syncthreads();
-  // symbols per macroblock, running sum (the segment has at most 256 macroblocks: one per thread)
+  wsync();
+  // symbols per macroblock, running sum (at most 32 macroblocks: one per lane)
   uint32_t v = 0;
-  if (tid < S.n) { const uint32_t nh = L.hoff[tid + 1] - L.hoff[tid]; v = L.p[tid] != 0xffffu ? nh - 1u + L.mc[tid] : nh; }
+  if (lane < S.n) { const uint32_t nh = L.hoff[lane + 1] - L.hoff[lane]; v = L.p[lane] != 0xffffu ? nh - 1u + L.mc[lane] : nh; }
   const uint32_t incl = (uint32_t)wave_scan_add ((int)v);
-  if ((tid & 63) == 63) L.wsum[tid >> 6] = incl;
-  __syncthreads();
-  uint32_t before = 0;
-  for (int w = 0; w < (tid >> 6); w++) before += L.wsum[w];
-  if (tid < S.n) L.sbase[tid] = before + incl - v;
-  if (tid == 255) L.sbase[S.n] = before + incl;
-  __syncthreads();
+  if (lane < S.n) L.sbase[lane] = incl - v;
+  if (lane == 63) L.sbase[S.n] = incl;
+  wsync();
   S.total = L.sbase[S.n];
 }
 // symbol s of the segment (coding order)
@@ -314,8 +386,8 @@ __device__ __forceinline__ uint64_t seg_symbol (const LDS SegLds& L, const Seg& 
 
 // ---- kernel 0: segments before each picture; which stream a picture belongs to ----------------------------------------------------
 __global__ void __launch_bounds__ (1024)
-coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __restrict__ chain_first, int n_jobs, int n_chains,
-                   uint32_t* __restrict__ seg0, uint32_t* __restrict__ job_chain, uint32_t* __restrict__ chain_info) {
+coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __restrict__ chain_first, int n_jobs, int n_chains, unsigned seg_bound,
+                   uint32_t* __restrict__ seg0, uint32_t* __restrict__ seg_job, uint32_t* __restrict__ job_chain, uint32_t* __restrict__ chain_info) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -329,59 +401,135 @@ coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __r
     __syncthreads();
     uint32_t before = carry;
     for (int w = 0; w < wave; w++) before += wsum[w];
-    if (j < n_jobs) seg0[j] = before + (uint32_t) (incl - v);
+    if (j < n_jobs) {
+      seg0[j] = before + (uint32_t) (incl - v);
+      for (uint32_t q = before + (uint32_t) (incl - v); q < before + (uint32_t)incl && q < seg_bound; q++) seg_job[q] = (uint32_t)j;
+    }
     __syncthreads();
     if (tid == 1023) carry = before + (uint32_t)incl;
     __syncthreads();
   }
   if (tid == 0) seg0[n_jobs] = carry;
+  // more segments than the caller's total_mbs made room for: the grids of the segment kernels would not reach all of them
+  const uint32_t st0 = carry > seg_bound ? (uint32_t)LH264_CODER_ST_COUNT : 0u;
   for (int c = tid; c < n_chains; c += 1024) {
     for (int j = chain_first[c]; j < chain_first[c + 1]; j++) job_chain[j] = (uint32_t)c;
-    chain_info[(size_t)c * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS] = 0;
+    chain_info[(size_t)c * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS] = st0;
     for (int q = 90; q < 96; q++) chain_info[(size_t)c * LH264_CODER_INFO_WORDS + q] = 0;
   }
 }
 
-// ---- kernel 1: decisions per tag of every segment ---------------------------------------------------------------------------------
+// ---- kernel 1: decisions per tag and per partition of every segment -----------------------------------------------------------------
 // seg_cnt[segment][0 .. LH264_N_TAG_SLOTS-1] decisions per tag slot (bit 31: the segment brings the tag's stream into existence),
-// [LH264_N_TAG_SLOTS] all decisions
-__global__ void __launch_bounds__ (256)
-coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, int n_jobs, uint32_t* __restrict__ seg_cnt) {
-  __shared__ SegLds Lg;
-  LDS SegLds& L = * (LDS SegLds*) (uintptr_t) (uint32_t) (uintptr_t)&Lg;
-  Seg S;
-  if (!seg_locate (jobs, seg0, n_jobs, blockIdx.x, S)) return;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 4 * (LH264_N_TAG_SLOTS + 2); i += 256) (&L.cnt[0][0])[i] = 0;
-  seg_layout (L, S, tid);
-  LDS uint32_t* cw = L.cnt[tid >> 6];
-  uint32_t tot = 0;
-  for (uint32_t s0 = 0; s0 < S.total; s0 += 256u) {
-    const uint32_t s = s0 + (uint32_t)tid;
-    if (s < S.total) {
-      const uint64_t sym = seg_symbol (L, S, s);
-      const uint32_t hi = (uint32_t) (sym >> 32);
-      const SymCount c = sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24));
-      if (c.s0 >= 0) __hip_atomic_fetch_add (&cw[c.s0], (uint32_t)c.n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (c.s1 >= 0) __hip_atomic_fetch_add (&cw[c.s1], (uint32_t)c.n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (c.s2 >= 0) __hip_atomic_fetch_add (&cw[c.s2], (uint32_t)c.n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (c.s3 >= 0) __hip_atomic_fetch_add (&cw[c.s3], (uint32_t)c.n3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (c.tch >= 0) __hip_atomic_fetch_or (&cw[c.tch], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      tot += (uint32_t)c.n;
-    }
-  }
-  tot = (uint32_t)__builtin_amdgcn_readlane (wave_scan_add ((int)tot), 63);
-  if ((tid & 63) == 0) cw[LH264_N_TAG_SLOTS] = tot;
-  __syncthreads();
-  if (tid <= LH264_N_TAG_SLOTS) {
-    const uint32_t a = L.cnt[0][tid], b = L.cnt[1][tid], c = L.cnt[2][tid], d = L.cnt[3][tid];
-    seg_cnt[(size_t)blockIdx.x * LH264_CODER_CNT_STRIDE + tid] = ((a + b + c + d) & 0x7fffffffu) | ((a | b | c | d) & 0x80000000u);
+// [LH264_N_TAG_SLOTS] all decisions; seg_part[segment][p] = decisions of the segment in partitions < p ([P]: all), i.e. where partition
+// p's run starts inside the segment's decision words.
+// Counters: one 16-bit column per lane in LDS ([slot][lane], two lanes to a dword) - the symbols of a step mostly count towards the
+// same few tags, and 64 lanes adding to one LDS word take 64 turns (that was the round-2 kernel's whole time); a lane's column is
+// its own bank.  A lane sees at most 16.9 K / 64 symbols of at most 46 decisions: the columns cannot overflow.
+// raw decisions behind emitInt's zero flag and sign (the mantissa bits beyond its four priors, man_place < 0)
+__device__ __forceinline__ int int_tail_raws (int data, int order) {
+  const int a = data - 1, high = 1 + (a >> order), l2 = 31 - __clz (high), nb = l2 + order;
+  if (nb <= 2) return 0;
+  auto mbit = [&] (int k) -> int { return k < l2 ? (high >> (l2 - 1 - k)) & 1 : (a >> ((order - 1 - (k - l2)) & 31)) & 1; };
+  return nb - 2 - ((!mbit (0) && !mbit (1)) ? 1 : 0);
+}
+#define CNT_SLOTS (LH264_N_TAG_SLOTS + 1)            // columns: the tag slots, then all decisions
+struct CountLds { SegLds seg; uint32_t col[CNT_SLOTS * 32]; uint32_t pcnt[LH264_CODER_MAX_PARTS]; };
+// the cell the decisions of a symbol use (trees over several cells: the first one), without its binarisation
+__device__ __forceinline__ uint32_t sym_key (uint32_t prior, int kind) {
+  switch (kind) {
+  case LH264_SYM_LUMA_DC: return LH264_PRIOR (LH264_TB_LDC, prior);
+  case LH264_SYM_CHROMA_DC: return LH264_PRIOR (LH264_TB_CDC, prior);
+  case LH264_SYM_NZ4: return LH264_PRIOR (LH264_TB_NZ4, prior);
+  case LH264_SYM_NZ8: return LH264_PRIOR (LH264_TB_NZ8, prior);
+  case LH264_SYM_AC4: return LH264_PRIOR (LH264_TB_AC4, prior);
+  case LH264_SYM_AC8: return LH264_PRIOR (LH264_TB_AC8, prior);
+  case LH264_SYM_RAW: return CODER_RAW_KEY;
+  default: return prior;
   }
 }
+__global__ void __launch_bounds__ (256)
+coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ seg_job, int n_jobs, int log2p,
+                    uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_part) {
+  __shared__ CountLds Lg[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  LDS CountLds& L = * (LDS CountLds*) (uintptr_t) (uint32_t) (uintptr_t)&Lg[wave];
+  const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
+  Seg S;
+  if (!seg_locate (jobs, seg0, seg_job, n_jobs, seg, S)) return;
+  for (int i = lane; i < CNT_SLOTS * 32; i += 64) L.col[i] = 0;
+  for (int i = lane; i < LH264_CODER_MAX_PARTS; i += 64) L.pcnt[i] = 0;
+  seg_layout (L.seg, S, lane);
+  LDS uint32_t* mycol = &L.col[lane >> 1];
+  const uint32_t sh = 16u * (uint32_t) (lane & 1);
+  auto add = [&] (int slot, uint32_t n) { __hip_atomic_fetch_add (mycol + slot * 32, n << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  // (the partitions: one counter each for the wave - the lanes of a step spread over them)
+  auto padd = [&] (uint32_t part, uint32_t n) { __hip_atomic_fetch_add (&L.pcnt[part], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  unsigned long long touch = 0;
+  const int P = 1 << log2p;
+  const uint32_t praw = cell_part (CODER_RAW_KEY, log2p);
+  for (uint32_t s0 = 0; s0 < S.total; s0 += 256u) {
+    // four symbols per lane and step: their loads are under way together
+    uint64_t sy[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint32_t s = s0 + 64u * (uint32_t)q + (uint32_t)lane; sy[q] = s < S.total ? seg_symbol (L.seg, S, s) : 0ull; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint64_t sym = sy[q];
+      const uint32_t prior = (uint32_t)sym, hi = (uint32_t) (sym >> 32);
+      const int value = (int) (int16_t) (hi & 0xffffu), kind = (int) ((hi >> 16) & 0xffu), pad = (int) (hi >> 24);
+      if (s0 + 64u * (uint32_t)q + (uint32_t)lane >= S.total) continue;
+      const SymCount c = sym_count (prior, value, kind, pad);
+      if (c.s0 >= 0) add (c.s0, (uint32_t)c.n0);
+      if (c.s1 >= 0) add (c.s1, (uint32_t)c.n1);
+      if (c.s2 >= 0) add (c.s2, (uint32_t)c.n2);
+      if (c.s3 >= 0) add (c.s3, (uint32_t)c.n3);
+      if (c.tch >= 0) touch |= 1ull << c.tch;
+      add (LH264_N_TAG_SLOTS, (uint32_t)c.n);
+      // partitions: the symbol's cell, TEST_PROB's for its raw bits; a tree over several cells is walked
+      const int table = (int) (prior >> 27);
+      const bool multi = (kind == LH264_SYM_TREE && (table == LH264_TB_SKIPRUN || table == LH264_TB_SUBMB)) || (kind == LH264_SYM_POW2 && table == LH264_TB_QPL);
+      if (multi) {
+        for (int j = 0; j < c.n; j++) padd (cell_part (decision_at (prior, value, kind, pad, j).key, log2p), 1u);
+      } else if (c.n > 0) {
+        int raws = 0;
+        const int av = value < 0 ? -value : value;
+        if (kind == LH264_SYM_RAW) raws = c.n;
+        else if (kind == LH264_SYM_LUMA_DC || kind == LH264_SYM_CHROMA_DC || kind == LH264_SYM_NZ4 || kind == LH264_SYM_NZ8) { if (value != 0) raws = int_tail_raws (av, 0); }
+        else if (kind == LH264_SYM_AC4 || kind == LH264_SYM_AC8) { if (av - 1 > 14) raws = int_tail_raws (av - 1 - 14, 0); }
+        else if (kind == LH264_SYM_MVD) { if (av - 1 > 9) raws = int_tail_raws (av - 1 - 9, 3); }
+        if (raws) padd (praw, (uint32_t)raws);
+        if (c.n > raws) padd (cell_part (sym_key (prior, kind), log2p), (uint32_t) (c.n - raws));
+      }
+    }
+  }
+  wsync();
+  // tags some symbol of the segment brought into existence: the same mask in every lane
+  for (int m = 1; m < 64; m <<= 1) touch |= (unsigned long long)__shfl_xor ((long long)touch, m);
+  // column sums: lane t adds up column t's 64 halves, every lane starting at a bank of its own
+  {
+    const int t = lane;
+    uint32_t sum = 0;
+    if (t < CNT_SLOTS)
+      for (int i = 0; i < 32; i++) { const uint32_t v = L.col[t * 32 + ((i + lane) & 31)]; sum += (v & 0xffffu) + (v >> 16); }
+    if (t < CNT_SLOTS) seg_cnt[(size_t)seg * LH264_CODER_CNT_STRIDE + t] = sum | (t < LH264_N_TAG_SLOTS ? (uint32_t) ((touch >> t) & 1ull) << 31 : 0u);
+  }
+  // the partitions: running sum -> where each partition's run starts inside the segment's words
+  GLB uint32_t* sp = glb<uint32_t> (seg_part) + (size_t)seg * (size_t) (P + 1);
+  uint32_t carry = 0;
+  for (int p0 = 0; p0 < P; p0 += 64) {
+    const uint32_t v = p0 + lane < P ? L.pcnt[p0 + lane] : 0u;
+    const uint32_t incl = (uint32_t)wave_scan_add ((int)v);
+    if (p0 + lane < P) sp[p0 + lane + 1] = carry + incl;
+    carry += (uint32_t)__builtin_amdgcn_readlane ((int)incl, 63);
+  }
+  if (lane == 0) sp[0] = 0;
+}
 
-// ---- kernel 2: per stream, where each segment's decisions start and the size of every tag's list ---------------------------------------
+// ---- kernel 2: per stream, where each segment's decisions start, where its entries of every tag's list start, the size of every list ---
+// seg_cnt[segment][t] becomes the number of entries of tag t's list in front of the segment (within the stream)
 __global__ void __launch_bounds__ (64)
-coder_scan_kernel (const uint32_t* __restrict__ seg0, const int32_t* __restrict__ chain_first, const uint32_t* __restrict__ seg_cnt,
+coder_scan_kernel (const uint32_t* __restrict__ seg0, const int32_t* __restrict__ chain_first, uint32_t* __restrict__ seg_cnt,
                    uint32_t* __restrict__ seg_doff, uint32_t* __restrict__ chain_info, int n_chains) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c >= n_chains) return;
@@ -389,11 +537,17 @@ coder_scan_kernel (const uint32_t* __restrict__ seg0, const int32_t* __restrict_
   uint32_t acc = 0, touched = 0;
   bool big = false;
   const int t = lane <= LH264_N_TAG_SLOTS ? lane : LH264_N_TAG_SLOTS;
-  const GLB uint32_t* p = glb<const uint32_t> (seg_cnt) + t;
-  for (size_t g = m0; g < m1; g++) {
-    const uint32_t v = p[g * LH264_CODER_CNT_STRIDE];
-    if (lane == LH264_N_TAG_SLOTS) { seg_doff[g] = acc; big = big || acc + v < acc; acc += v; }
-    else { acc += v & 0x7fffffffu; touched |= v >> 31; }
+  GLB uint32_t* p = glb<uint32_t> (seg_cnt) + t;
+  for (size_t g0 = m0; g0 < m1; g0 += 8) {                 // (eight segments' counts under way at a time)
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = g0 + k < m1 ? p[(g0 + k) * LH264_CODER_CNT_STRIDE] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (g0 + k >= m1) break;
+      if (lane == LH264_N_TAG_SLOTS) { seg_doff[g0 + k] = acc; big = big || acc + v[k] < acc; acc += v[k]; }
+      else if (lane < LH264_N_TAG_SLOTS) { p[(g0 + k) * LH264_CODER_CNT_STRIDE] = acc; acc += v[k] & 0x7fffffffu; touched |= v[k] >> 31; }
+    }
   }
   uint32_t* I = chain_info + (size_t)c * LH264_CODER_INFO_WORDS;
   // tag lists are padded to 8 entries (16 bytes): the coding kernel reads them 16 bytes at a time
@@ -403,7 +557,9 @@ coder_scan_kernel (const uint32_t* __restrict__ seg0, const int32_t* __restrict_
   const unsigned long long tm = __ballot (lane < LH264_N_TAG_SLOTS && touched != 0);
   if (lane == LH264_N_TAG_SLOTS) { I[LH264_CODER_INFO_NDEC] = acc; I[LH264_CODER_INFO_TOUCH] = (uint32_t)tm; I[LH264_CODER_INFO_TOUCH + 1] = (uint32_t) (tm >> 32); }
   if (lane == 63) I[LH264_CODER_INFO_NQ] = incl;
-  if (__ballot (big) && lane == 0) atomicOr (&I[LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_COUNT);      // more than 2^32 decisions in a stream
+  // more than 2^32 decisions in a stream, or more list entries than a decision word can address
+  const uint32_t nq = (uint32_t)__builtin_amdgcn_readlane ((int)incl, 63);
+  if ((__ballot (big) || nq >= (1u << CODER_QPOS_BITS)) && lane == 0) atomicOr (&I[LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_COUNT);
 }
 
 // ---- kernel 3: where each stream's decision words and tag lists start (prefix over the streams); the totals for the host -------
@@ -441,54 +597,6 @@ coder_bases_kernel (uint32_t* __restrict__ chain_info, int n_chains, unsigned lo
   if (tid == 0) { totals[0] = cd; totals[1] = cq; }
 }
 
-// ---- kernel 4: the decision words, in coding order -------------------------------------------------------------------------
-// The four waves of a segment's workgroup take a quarter of its symbols each: first how many decisions the quarter makes, then, behind
-// a barrier, the words from where the quarters before it end.
-__global__ void __launch_bounds__ (256)
-coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ job_chain,
-                   int n_jobs, const uint32_t* __restrict__ seg_doff, const uint32_t* __restrict__ chain_info, uint64_t* __restrict__ D) {
-  __shared__ SegLds Lg;
-  __shared__ uint32_t qtot[4];
-  LDS SegLds& L = * (LDS SegLds*) (uintptr_t) (uint32_t) (uintptr_t)&Lg;
-  Seg S;
-  if (!seg_locate (jobs, seg0, n_jobs, blockIdx.x, S)) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  seg_layout (L, S, tid);
-  const uint32_t* I = chain_info + (size_t)job_chain[S.job] * LH264_CODER_INFO_WORDS;
-  const unsigned long long dbase = ((unsigned long long)I[LH264_CODER_INFO_DBASE] | (unsigned long long)I[LH264_CODER_INFO_DBASE + 1] << 32) + seg_doff[blockIdx.x];
-  const uint32_t per = (S.total + 3u) >> 2, s_lo = min ((uint32_t)wave * per, S.total), s_hi = min (s_lo + per, S.total);
-  uint32_t mine = 0;
-  for (uint32_t s0 = s_lo; s0 < s_hi; s0 += 64u) {
-    const uint32_t s = s0 + (uint32_t)lane;
-    if (s < s_hi) {
-      const uint64_t sym = seg_symbol (L, S, s);
-      const uint32_t hi = (uint32_t) (sym >> 32);
-      mine += (uint32_t)sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24)).n;
-    }
-  }
-  const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane (wave_scan_add ((int)mine), 63);
-  if (lane == 0) qtot[wave] = wtot;
-  __syncthreads();
-  uint32_t running = 0;
-  for (int w = 0; w < wave; w++) running += qtot[w];
-  for (uint32_t s0 = s_lo; s0 < s_hi; s0 += 64u) {
-    const uint32_t s = s0 + (uint32_t)lane;
-    uint64_t sym = 0; uint32_t hi = 0; int n = 0;
-    if (s < s_hi) {
-      sym = seg_symbol (L, S, s);
-      hi = (uint32_t) (sym >> 32);
-      n = sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24)).n;
-    }
-    const int incl = wave_scan_add (n);
-    if (n > 0) {
-      EmitSink es; es.D = glb<uint64_t> (D) + dbase; es.pos = running + (uint32_t) (incl - n); es.key = 0;
-      binarize (es, (uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24));
-    }
-    running += (uint32_t)__builtin_amdgcn_readlane (incl, 63);
-  }
-}
-
-// ---- kernel 5: the probability every decision is coded with -----------------------------------------------------------------
 // which lanes of the wave hold the same `nbits`-bit key as this lane (valid lanes only)
 template <int NBITS> __device__ __forceinline__ void wave_match (uint32_t key, unsigned long long valid, uint32_t& lo, uint32_t& hi) {
   uint32_t dlo = 0, dhi = 0;
@@ -502,92 +610,201 @@ template <int NBITS> __device__ __forceinline__ void wave_match (uint32_t key, u
 }
 __device__ __forceinline__ int below (uint32_t lo, uint32_t hi) { return (int)__builtin_amdgcn_mbcnt_hi (hi, __builtin_amdgcn_mbcnt_lo (lo, 0u)); }
 
-// The counters of a DynProb as the resolve kernel keeps them: c0 | c1 << 10, NOT yet halved when their sum has reached 513 - the
-// reference computes the next probability before it halves (DynProb::update, :101-113), so the probability of the next decision always
-// follows from the stored pair, and the halving is done by the next reader.  An entry of the LDS cache (and of the spill table in HBM) is
-// 64 bits: counters in bits 0..19, the DynProb's key (cell key << 4 | place, 36 bits) in bits 20..55, bit 63 set.  All zero = free.
-#define RS_WAVES LH264_CODER_RESOLVE_WAVES
-// diagnostic build (-DLH264_CODER_DEBUG): shader-clock stamps of the resolve kernel's phases, summed over the waves of a stream into
-// chain_info words 90..94 (in units of 1024 cycles), reported in the unused length slots 35..39
+// ---- kernel 4: the decision words ------------------------------------------------------------------------------------------------
+// One wave per segment, a lane per DECISION: the wave takes 256 symbols of the segment at a time, lays their decision counts out as a
+// running sum, and then every lane of a step finds the symbol its decision belongs to (binary search in LDS) and computes the decision
+// in closed form (decision_at) - no lane walks a binarisation while its neighbours with shorter symbols idle.  A decision word goes to
+// the run of its partition inside the segment's words (stable: coding order inside a partition), and carries the entry of its tag's
+// list it will fill; both places are running counts in coding order: lanes with the same partition / tag find each other with ballots
+// (wave_match), cursors per partition and per tag live in the wave's LDS.
+#define EMIT_BATCH 256
+struct EmitLds {
+  SegLds seg;
+  uint64_t bsym[EMIT_BATCH];         // the batch's symbols (those with decisions)
+  uint16_t bS[EMIT_BATCH];           // decisions of the batch in front of symbol i
+  uint32_t starts[EMIT_BATCH * 46 / 32 + 2];      // bit d: a symbol's decisions start at decision d of the batch
+  uint32_t tcur[LH264_N_TAG_SLOTS];  // next entry of each tag's list (within the stream's lists)
+  uint32_t pcur[LH264_CODER_MAX_PARTS];   // next word of each partition's run (within the segment's words)
+};
+__global__ void __launch_bounds__ (256)
+coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ seg_job, const uint32_t* __restrict__ job_chain,
+                   int n_jobs, int log2p, const uint32_t* __restrict__ seg_doff, const uint32_t* __restrict__ seg_cnt, const uint32_t* __restrict__ seg_part,
+                   const uint32_t* __restrict__ chain_info, uint64_t* __restrict__ D) {
+  __shared__ EmitLds Lg[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  LDS EmitLds& L = * (LDS EmitLds*) (uintptr_t) (uint32_t) (uintptr_t)&Lg[wave];
+  const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
+  Seg S;
+  if (!seg_locate (jobs, seg0, seg_job, n_jobs, seg, S)) return;
+  seg_layout (L.seg, S, lane);
+  const uint32_t* I = chain_info + (size_t)job_chain[S.job] * LH264_CODER_INFO_WORDS;
+  GLB uint64_t* Dseg = glb<uint64_t> (D) + ((unsigned long long)I[LH264_CODER_INFO_DBASE] | (unsigned long long)I[LH264_CODER_INFO_DBASE + 1] << 32) + seg_doff[seg];
+  if (lane < LH264_N_TAG_SLOTS) L.tcur[lane] = I[LH264_CODER_INFO_TAGBASE + lane] + seg_cnt[(size_t)seg * LH264_CODER_CNT_STRIDE + lane];
+  for (int i = lane; i < (1 << log2p); i += 64) L.pcur[i] = seg_part[(size_t)seg * (size_t) ((1 << log2p) + 1) + i];
+  wsync();
+  for (uint32_t b0 = 0; b0 < S.total; b0 += EMIT_BATCH) {
+    // the batch: symbols b0 .. b0 + 255 (four per lane, their loads under way together); those with decisions are kept, in coding
+    // order, with the number of the batch's decisions in front of each, and a bit is set where each one's decisions start
+    for (int i = lane; i < EMIT_BATCH * 46 / 32 + 2; i += 64) L.starts[i] = 0;
+    uint64_t sy[EMIT_BATCH / 64];
+#pragma unroll
+    for (int q = 0; q < EMIT_BATCH / 64; q++) { const uint32_t s = b0 + 64u * (uint32_t)q + (uint32_t)lane; sy[q] = s < S.total ? seg_symbol (L.seg, S, s) : 0ull; }
+    wsync();
+    uint32_t run = 0, kept = 0;
+#pragma unroll
+    for (int q = 0; q < EMIT_BATCH / 64; q++) {
+      const uint64_t sym = sy[q];
+      const uint32_t hi = (uint32_t) (sym >> 32);
+      const int n = b0 + 64u * (uint32_t)q + (uint32_t)lane < S.total ? sym_count ((uint32_t)sym, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24)).n : 0;
+      const int incl = wave_scan_add (n);
+      const unsigned long long km = __ballot (n > 0);
+      if (n > 0) {
+        const uint32_t k = kept + (uint32_t)below ((uint32_t)km, (uint32_t) (km >> 32)), st = run + (uint32_t) (incl - n);
+        L.bsym[k] = sym; L.bS[k] = (uint16_t)st;
+        __hip_atomic_fetch_or (&L.starts[st >> 5], 1u << (st & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      kept += (uint32_t)__popcll (km);
+      run += (uint32_t)__builtin_amdgcn_readlane (incl, 63);
+    }
+    wsync();
+    const uint32_t T = run;                                 // decisions of the batch (< 2^16: 256 symbols of at most 46)
+    uint32_t kbase = 0;                                     // symbols that start in front of the step's first decision
+    for (uint32_t d0 = 0; d0 < T; d0 += 64u) {
+      const bool valid = d0 + (uint32_t)lane < T;
+      // the symbol of this lane's decision: the last one that starts at or before it = a count over the start bits
+      const uint32_t mlo = * (volatile LDS uint32_t*)&L.starts[d0 >> 5], mhi = * (volatile LDS uint32_t*)&L.starts[(d0 >> 5) + 1u];
+      const uint32_t upto = (uint32_t)__builtin_amdgcn_mbcnt_hi (mhi, __builtin_amdgcn_mbcnt_lo (mlo, 0u)) + (uint32_t) (((lane < 32 ? mlo >> lane : mhi >> (lane - 32)) & 1u));
+      const uint32_t lo = min (kbase + upto - 1u, kept - 1u);
+      kbase += (uint32_t)__popc (mlo) + (uint32_t)__popc (mhi);
+      const uint32_t d = valid ? d0 + (uint32_t)lane : (uint32_t)L.bS[lo];
+      const uint64_t sym = L.bsym[lo];
+      const uint32_t shi = (uint32_t) (sym >> 32);
+      const Decision dc = decision_at ((uint32_t)sym, (int) (int16_t) (shi & 0xffffu), (int) ((shi >> 16) & 0xffu), (int) (shi >> 24), (int) (d - (uint32_t)L.bS[lo]));
+      const uint32_t part = cell_part (dc.key, log2p);
+      const unsigned long long vm = __ballot (valid);
+      uint32_t tlo, thi, plo, phi;
+      wave_match<6> ((uint32_t)dc.tag, vm, tlo, thi);
+      if (log2p <= 4) wave_match<4> (part, vm, plo, phi); else wave_match<LH264_CODER_MAX_LOG2P> (part, vm, plo, phi);
+      const int trank = below (tlo, thi), tn = __popc (tlo) + __popc (thi), prank = below (plo, phi), pn = __popc (plo) + __popc (phi);
+      volatile LDS uint32_t* tc = &L.tcur[dc.tag];
+      volatile LDS uint32_t* pc = &L.pcur[part];
+      uint32_t tb = 0, pb = 0;
+      if (valid) { tb = *tc; pb = *pc; }
+      asm volatile ("" ::: "memory");
+      if (valid && trank == tn - 1) *tc = tb + (uint32_t)tn;
+      if (valid && prank == pn - 1) *pc = pb + (uint32_t)pn;
+      if (valid)
+        Dseg[pb + (uint32_t)prank] = (uint64_t)dc.key | (uint64_t) ((uint32_t)dc.place | (uint32_t)dc.bit << 4 | ((tb + (uint32_t)trank) & ((1u << CODER_QPOS_BITS) - 1u)) << 5) << 32;
+    }
+    wsync();
+  }
+}
+
+// ---- kernel 5: the probability every decision is coded with -----------------------------------------------------------------
+// One wave per (stream, partition): the DynProbs of a partition belong to that wave alone, so nothing is shared between waves - no
+// ticket, no workgroup barrier (round 2 resolved a stream with one workgroup whose waves took turns on shared counters: 46 % of a
+// wave's time was waiting for its turn).  A partition's decision words are the runs the binarisation left in every segment of the
+// stream, in order; the wave packs them into rounds of 64 (a round may span runs).  Per round: lanes holding the same DynProb find each
+// other with ballots; the probability a decision is coded with follows from the counters before the round plus the PREFIX COUNTS of the
+// earlier decisions of the round on the same DynProb; the last lane of a group writes the counters back.  The entry (probability of the
+// bit that occurred, bit) goes to the place of the tag's list the word names.
+// The counters of a DynProb as kept here: c0 | c1 << 10, NOT yet halved when their sum has reached 513 - the reference computes the next
+// probability before it halves (DynProb::update, :101-113), so the probability of the next decision always follows from the stored pair,
+// and the halving is done by the next reader.  An entry of the wave's LDS cache (and of the spill table in HBM) is 64 bits: counters in
+// bits 0..19, the DynProb's key (cell key << 4 | place, 36 bits) in bits 20..55, bit 63 set.  All zero = free.
+#define R2_WAVES 4
+#define R2_LOG2_BUCKETS 8
+#define R2_SLOTS (4 << R2_LOG2_BUCKETS)        // DynProbs in a wave's LDS cache: 1024
+// Decision words are requested R2_DEPTH + 3 rounds before they are resolved (a round takes about 0.5 us, a word under load 2 .. 3 us to arrive)
+#define R2_DEPTH 6
+#define R2_CHECK 4               // the fill of the cache is looked at every R2_CHECK rounds (that many rounds insert <= 256)
+#ifndef R2_FLUSH
+#define R2_FLUSH 600             // everything goes to the spill table and the cache starts over above this many
+#endif
+// diagnostic build (-DLH264_CODER_DEBUG): shader-clock stamps of the resolve kernel's phases, summed over all waves (never in product builds)
 #ifdef LH264_CODER_DEBUG
-#define RS_STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[6] = {0, 0, 0, 0, 0, 0};
+__device__ unsigned long long g_rs_stamps[16];
+#define RS_STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define RS_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
-#define RS_STAMP_FLUSH if (lane == 0) for (int q_ = 0; q_ < 6; q_++) atomicAdd (&chain_info[(size_t)chain * LH264_CODER_INFO_WORDS + 90 + q_], (uint32_t) (st_acc[q_] >> 10));
+#define RS_STAMP_FLUSH if (lane == 0) for (int q_ = 0; q_ < 10; q_++) atomicAdd (&g_rs_stamps[q_], st_acc[q_]);
 #else
 #define RS_STAMP_DECL
 #define RS_STAMP(i)
 #define RS_STAMP_FLUSH
 #endif
-#define RS_LOG2_BUCKETS 11
-#define RS_SLOTS (4 << RS_LOG2_BUCKETS)        // DynProbs in the LDS cache: 8192
-#define RS_CHECK 4               // the fill of the cache is looked at every RS_CHECK workgroup steps (that many steps insert <= 2048)
-#ifndef RS_FLUSH
-#define RS_FLUSH 4600            // everything goes to the spill table and the cache starts over above this many
-#endif
 struct ResolveLds {
-  unsigned long long ent[RS_SLOTS];
-  uint32_t cursor[LH264_N_TAG_SLOTS];
-  uint32_t test_prob;            // TEST_PROB: the DynProb shared by the raw bits of all tags
-  uint32_t ticket;               // the next wave step allowed into the serial section
-  uint32_t nres;                 // entries in the cache
-  uint32_t flush_step;           // the last workgroup step at whose end the cache is (was) flushed
-  uint32_t scratch[RS_WAVES][64];
-  uint32_t ring[RS_WAVES][3][2][64];       // per wave: the decision words of three future rounds (low dwords, high dwords), filled by LDS-DMA
+  unsigned long long ent[R2_SLOTS];
+  uint32_t ring[R2_DEPTH][2][64];   // the decision words of R2_DEPTH future rounds (low dwords, high dwords), filled by LDS-DMA
+  uint32_t scratch[64];
+  uint32_t nres, pad[3];
 };
-__device__ __forceinline__ unsigned long long rs_key (uint32_t lo, uint32_t hi) { return (unsigned long long)lo << 4 | (unsigned long long) (hi & 15u); }
-#define RS_ENT_KEY(e) (((e) >> 20) & 0xfffffffffull)
-#define RS_ENT_MAKE(key, st) (0x8000000000000000ull | (unsigned long long) (key) << 20 | (unsigned long long) (st))
-__device__ __forceinline__ uint32_t rs_hash (unsigned long long key) { return ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t) (key >> 32) * 0x85EBCA6Bu); }
+// An entry of a wave's LDS cache (and of the spill table): low dword = the key of the DynProb's cell, high dword = 0x10 | place in
+// bits 27..31 (never zero for an entry in use), the counters in bits 0..19.  All zero = free.
+typedef unsigned long long u64;
+#define RS_KEYMASK 0xf8000000ffffffffull
+__device__ __forceinline__ u64 ent_make (uint32_t klo, uint32_t place, uint32_t st) { return (u64)klo | (u64) ((0x10u | place) << 27 | st) << 32; }
+__device__ __forceinline__ uint32_t rs_hash (uint32_t klo, uint32_t place) { return (klo + place * 0x61C88647u) * 0x9E3779B1u; }
+__device__ __forceinline__ uint32_t ent_hash (u64 e) { return rs_hash ((uint32_t)e, (uint32_t) (e >> 59) & 15u); }
 
-// the spill table: open addressing over the stream's `hash_cells_dev` memory (zero-filled by the caller), entries as above.  Only this
-// workgroup touches it; its accesses go to L2 (agent scope), never through this CU's L1.
-__device__ __forceinline__ bool spill_put (GLB unsigned long long* T, uint32_t tmask, unsigned long long key, uint32_t st) {
-  const unsigned long long val = RS_ENT_MAKE (key, st);
-  uint32_t h = rs_hash (key) >> 8;
+// the spill table of a partition: open addressing over its share of the stream's `hash_cells_dev` memory (zero-filled by the caller),
+// entries as above.  Only this wave touches it (two of its lanes may want the same free slot: compare-and-swap); its accesses go to L2
+// (agent scope), never through this CU's L1.
+__device__ __forceinline__ bool spill_put (GLB u64* T, uint32_t tmask, u64 e, uint32_t skip) {
+  uint32_t h = (ent_hash (e) >> 8) + skip;
   for (uint32_t tries = 0; tries <= tmask; tries++, h++) {
-    GLB unsigned long long* p = T + (h & tmask);
-    unsigned long long cur = __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == 0ull) { unsigned long long expect = 0ull; if (__hip_atomic_compare_exchange_strong (p, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true; cur = expect; }
-    if (RS_ENT_KEY (cur) == key) { __hip_atomic_store (p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }      // (a key sits in one cache entry: nobody else writes it now)
+    GLB u64* p = T + (h & tmask);
+    u64 cur = __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0ull) { u64 expect = 0ull; if (__hip_atomic_compare_exchange_strong (p, &expect, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true; cur = expect; }
+    if (((cur ^ e) & RS_KEYMASK) == 0ull) { __hip_atomic_store (p, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
     if (tries >= 4096u) break;
   }
   return false;                  // the table is (as good as) full
 }
-__device__ __forceinline__ uint32_t spill_get (const GLB unsigned long long* T, uint32_t tmask, unsigned long long key, unsigned long long first) {
-  uint32_t h = rs_hash (key) >> 8;
-  unsigned long long cur = first;                   // the entry at the key's home slot, requested a step ago
+__device__ __forceinline__ uint32_t spill_get (const GLB u64* T, uint32_t tmask, u64 key, u64 first) {
+  uint32_t h = ent_hash (key) >> 8;
+  u64 cur = first;                                  // the entry at the key's home slot, requested a round ago
   for (uint32_t tries = 0; tries <= tmask; tries++) {
     if (cur == 0ull) return 0u;
-    if (RS_ENT_KEY (cur) == key) return (uint32_t)cur & 0xfffffu;
+    if (((cur ^ key) & RS_KEYMASK) == 0ull) return (uint32_t) (cur >> 32) & 0xfffffu;
     h++;
     cur = __hip_atomic_load (T + (h & tmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   return 0u;
 }
 
-struct SlotRef { int idx; bool miss, inserted; unsigned long long first; };
+struct SlotRef { int idx; bool miss, inserted; u64 first;
+#ifdef LH264_CODER_DEBUG
+  int iters;
+#endif
+};
 // the cache entry of the DynProb of decision word (lo, hi): inserted with fresh counters if absent; if counters may have been spilled,
 // the inserting lane asks the spill table (answer taken by rs_land)
-__device__ __forceinline__ void rs_lookup (LDS ResolveLds& S, const GLB unsigned long long* T, uint32_t tmask, uint32_t lo, uint32_t hi, bool valid, bool spilled, SlotRef& R) {
+__device__ __forceinline__ void rs_lookup (LDS ResolveLds& S, const GLB u64* T, uint32_t tmask, uint32_t lo, uint32_t hi, bool valid, bool spilled, SlotRef& R) {
+#ifdef LH264_CODER_DEBUG
+  R.iters = 0;
+#endif
   R.idx = 0; R.miss = false; R.inserted = false; R.first = 0ull;
-  if (valid && !(hi & 0x80000000u)) {
-    const unsigned long long key = rs_key (lo, hi), fresh = RS_ENT_MAKE (key, 0u);
+  if (valid) {
+    const uint32_t place = hi & 15u, kt = (0x10u | place) << 27;
+    const u64 fresh = ent_make (lo, place, 0u);
     // buckets of four entries (32 bytes, read at once): a probe looks at a whole bucket, so the longest probe sequence among the 64
     // lanes of a wave - which is what the wave waits for - stays short
-    uint32_t bkt = rs_hash (key) >> (32 - RS_LOG2_BUCKETS), h = 0;
-    for (int tries = 0; tries < RS_SLOTS / 4; tries++, bkt++) {      // (the flush policy keeps the cache at most 7/8 full: bounded anyway)
-      bkt &= RS_SLOTS / 4 - 1;
+    const uint32_t hh = rs_hash (lo, place);
+    uint32_t bkt = hh >> (32 - R2_LOG2_BUCKETS), h = 0;
+    for (int tries = 0; tries < R2_SLOTS / 4; tries++, bkt++) {      // (the flush policy keeps the cache at most 7/8 full: bounded anyway)
+      bkt &= R2_SLOTS / 4 - 1;
+#ifdef LH264_CODER_DEBUG
+      R.iters++;
+#endif
       const LDS u32x4* bp = (const LDS u32x4*)&S.ent[4u * bkt];
       const u32x4 a = * (volatile const LDS u32x4*)bp, b = * (volatile const LDS u32x4*) (bp + 1);
-      const unsigned long long e[4] = {(unsigned long long)a.x | (unsigned long long)a.y << 32, (unsigned long long)a.z | (unsigned long long)a.w << 32,
-                                       (unsigned long long)b.x | (unsigned long long)b.y << 32, (unsigned long long)b.z | (unsigned long long)b.w << 32};
-      int found = -1, empty = -1;
-#pragma unroll
-      for (int q = 3; q >= 0; q--) { if (e[q] == 0ull) empty = q; if (e[q] != 0ull && RS_ENT_KEY (e[q]) == key) found = q; }
-      if (found >= 0) { h = 4u * bkt + (uint32_t)found; break; }
+      const bool m0 = a.x == lo && (a.y & 0xf8000000u) == kt, m1 = a.z == lo && (a.w & 0xf8000000u) == kt,
+                 m2 = b.x == lo && (b.y & 0xf8000000u) == kt, m3 = b.z == lo && (b.w & 0xf8000000u) == kt;
+      if (m0 || m1 || m2 || m3) { h = 4u * bkt + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u); break; }
+      const int empty = a.y == 0u ? 0 : a.w == 0u ? 1 : b.y == 0u ? 2 : b.w == 0u ? 3 : -1;
       if (empty >= 0) {
         // take the first free entry of the bucket; if another lane is quicker, look at the bucket again (it may have put this very key there)
-        unsigned long long expect = 0ull;
+        u64 expect = 0ull;
         if (__hip_atomic_compare_exchange_strong (&S.ent[4u * bkt + (uint32_t)empty], &expect, fresh, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
           h = 4u * bkt + (uint32_t)empty; R.miss = true; break;
         }
@@ -597,65 +814,114 @@ __device__ __forceinline__ void rs_lookup (LDS ResolveLds& S, const GLB unsigned
     R.idx = (int)h;
     R.inserted = R.miss;
     R.miss = R.miss && spilled;                                // before the first flush a new DynProb is simply fresh
-    if (R.miss) R.first = __hip_atomic_load (T + ((rs_hash (key) >> 8) & tmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the spill table is asked in rs_land, a round later, and waited for there: a load the compiler sees under way ACROSS iterations
+    // makes it drain every request under way - "s_waitcnt vmcnt(0)" - in every iteration, needed or not)
   }
 }
 // the counters the spill table holds for an entry inserted by rs_lookup go into the entry (it has not been used yet)
-__device__ __forceinline__ void rs_land (LDS ResolveLds& S, const GLB unsigned long long* T, uint32_t tmask, uint32_t lo, uint32_t hi, SlotRef& R) {
+__device__ __forceinline__ void rs_land (LDS ResolveLds& S, const GLB u64* T, uint32_t tmask, uint32_t lo, uint32_t hi, SlotRef& R) {
   if (R.miss) {
-    const uint32_t st = spill_get (T, tmask, rs_key (lo, hi), R.first);
-    volatile LDS uint32_t* p = (volatile LDS uint32_t*)&S.ent[R.idx];
+    const u64 key = ent_make (lo, hi & 15u, 0u);
+    const uint32_t st = spill_get (T, tmask, key, __hip_atomic_load (T + ((ent_hash (key) >> 8) & tmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    volatile LDS uint32_t* p = (volatile LDS uint32_t*)&S.ent[R.idx] + 1;
     if (st) *p = (*p & 0xfff00000u) | st;
     R.miss = false;
   }
 }
-__device__ __forceinline__ void rs_count (LDS ResolveLds& S, bool inserted, int lane) {
-  const unsigned long long mm = __ballot (inserted);
-  if (mm && lane == 0) __hip_atomic_fetch_add (&S.nres, (uint32_t)__popcll (mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// LDS traffic of this wave done, then the workgroup barrier (not __syncthreads: it would also wait for the memory operations in flight)
-__device__ __forceinline__ void rs_barrier() {
-  asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile ("" ::: "memory");
+// every DynProb of the cache to the spill table, the cache cleared.  Four entries per lane at a time: their home slots are read
+// together and taken together (one memory round trip each instead of one per entry); what finds its home slot taken by another key
+// goes the slow way.
+__device__ __forceinline__ bool rs_flush (LDS ResolveLds& S, GLB u64* T, uint32_t tmask, int lane) {
+  bool ok = true;
+  for (int u0 = 0; u0 < R2_SLOTS / 64; u0 += 4) {
+    u64 e[4], cur[4]; GLB u64* hp[4]; bool took[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { e[u] = S.ent[lane + 64 * (u0 + u)]; hp[u] = T + ((ent_hash (e[u]) >> 8) & tmask); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) cur[u] = e[u] ? __hip_atomic_load (hp[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      took[u] = false;
+      if (cur[u] == 0ull) { u64 expect = 0ull; took[u] = __hip_atomic_compare_exchange_strong (hp[u], &expect, e[u], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cur[u] = expect; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (e[u] && !took[u]) {
+        if (((cur[u] ^ e[u]) & RS_KEYMASK) == 0ull) __hip_atomic_store (hp[u], e[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else ok = spill_put (T, tmask, e[u], 1u) && ok;
+      }
+      S.ent[lane + 64 * (u0 + u)] = 0ull;
+    }
+  }
+  return ok;
 }
 
-// Workgroup step `it` = rounds it * RS_WAVES .. + RS_WAVES - 1 of 64 decisions, one per wave, through the ticketed serial section in
-// round order; nothing else synchronises the waves of a step.  Software pipeline per wave: the decision words are fetched five steps
-// ahead; the cache entries of a round are looked up two steps before the round is resolved (a DynProb that is not in the cache is
-// inserted then, and its spilled counters requested); the answer goes into the entry one step later, BEFORE the wave's own turn of
-// that step - every round that uses the entry comes later in ticket order than that turn, so it sees the counters.
-__global__ void __launch_bounds__ (RS_WAVES * 64)
-coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t* __restrict__ chain_info, const uint64_t* __restrict__ D,
-                      uint16_t* __restrict__ Q, int n_chains) {
-  __shared__ ResolveLds Sg;
-  LDS ResolveLds& S = * (LDS ResolveLds*) (uintptr_t) (uint32_t) (uintptr_t)&Sg;
-  const int chain = blockIdx.x;
+// the rounds of a partition: its runs of decision words in the segments [g, g_end) of the stream, packed 64 to a round.  The run of
+// the next segment is looked up (scalar loads from the segment tables) when the current one is opened, a run ahead of its use.
+struct RoundGen {
+  uint32_t g, g_end, part, pstride;
+  u64 dbase, cur; uint32_t rem;
+  uint32_t nx_o0, nx_o1, nx_doff;                         // segment g's table entries, requested ahead
+  __device__ __forceinline__ void request (const uint32_t* __restrict__ seg_doff, const uint32_t* __restrict__ seg_part) {
+    const uint32_t gg = g < g_end ? g : g_end - 1u;         // (always a valid segment: the stream has one when it has a round)
+    nx_o0 = seg_part[(size_t)gg * pstride + part]; nx_o1 = seg_part[(size_t)gg * pstride + part + 1u]; nx_doff = seg_doff[gg];
+  }
+  // the words of the next round: index of this lane's word (any valid index for a lane beyond the count), the count (0: no more rounds)
+  __device__ __forceinline__ uint32_t next (const uint32_t* __restrict__ seg_doff, const uint32_t* __restrict__ seg_part, int lane, u64& idx) {
+    uint32_t c = min (rem, 64u);
+    idx = cur + (uint32_t)lane;
+    cur += c; rem -= c;
+    while (c < 64u && g < g_end) {
+      const uint32_t len = nx_o1 - nx_o0;
+      const u64 b = dbase + nx_doff + nx_o0;
+      g++;
+      request (seg_doff, seg_part);
+      if (len == 0u) continue;
+      const uint32_t take = min (len, 64u - c);
+      if ((uint32_t)lane >= c) idx = b + ((uint32_t)lane - c);
+      cur = b + take; rem = len - take; c += take;
+    }
+    if ((uint32_t)lane >= c) idx = dbase;
+    return c;
+  }
+};
+
+__global__ void __launch_bounds__ (R2_WAVES * 64)
+coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t* __restrict__ chain_info, const uint32_t* __restrict__ seg0,
+                      const int32_t* __restrict__ chain_first, const uint32_t* __restrict__ seg_doff, const uint32_t* __restrict__ seg_part,
+                      const uint64_t* __restrict__ D, uint16_t* __restrict__ Q, int n_chains, int log2p) {
+  __shared__ ResolveLds Sg[R2_WAVES];
+  const int lane = threadIdx.x & 63, wave = uniform ((int) (threadIdx.x >> 6));
+  LDS ResolveLds& S = * (LDS ResolveLds*) (uintptr_t) (uint32_t) (uintptr_t)&Sg[wave];
+  const uint32_t wid = blockIdx.x * R2_WAVES + (uint32_t)wave;      // (stream, partition)
+  const int chain = (int) (wid >> log2p);
+  const uint32_t part = wid & ((1u << log2p) - 1u);
   if (chain >= n_chains) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const uint32_t* I = chain_info + (size_t)chain * LH264_CODER_INFO_WORDS;
-  const uint32_t n = I[LH264_CODER_INFO_NDEC];
-  const GLB uint64_t* Dc = glb<const uint64_t> (D) + ((unsigned long long)I[LH264_CODER_INFO_DBASE] | (unsigned long long)I[LH264_CODER_INFO_DBASE + 1] << 32);
+  uint32_t* I = chain_info + (size_t)chain * LH264_CODER_INFO_WORDS;
+  // the partition's share of the stream's spill table (hash_cap cells of 64 bytes = 8 entries each)
+  const uint32_t hc = streams[chain].hash_cap;
+  if (hc == 0u || (hc & (hc - 1u)) != 0u || hc > (1u << 20) || ((hc * 8u) >> log2p) < 64u) {
+    if (lane == 0) atomicOr (&I[LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_TABLE_FULL);
+    return;
+  }
+  const uint32_t tsize = (hc * 8u) >> log2p, tmask = tsize - 1u;
+  GLB u64* T = glb<u64> (streams[chain].hash_cells_dev) + (size_t)part * tsize;
   GLB uint16_t* Qc = glb<uint16_t> (Q) + ((unsigned long long)I[LH264_CODER_INFO_QBASE] | (unsigned long long)I[LH264_CODER_INFO_QBASE + 1] << 32);
-  GLB unsigned long long* T = glb<unsigned long long> (streams[chain].hash_cells_dev);
-  const uint32_t tmask = streams[chain].hash_cap * 8u - 1u;            // hash_cap cells of 64 bytes = 8 entries each
-  for (int i = tid; i < RS_SLOTS; i += RS_WAVES * 64) S.ent[i] = 0ull;
-  if (tid < LH264_N_TAG_SLOTS) S.cursor[tid] = I[LH264_CODER_INFO_TAGBASE + tid];
-  if (tid == 0) { S.test_prob = 0; S.ticket = 0; S.nres = 0; S.flush_step = 0xffffffffu; }
-  __syncthreads();
-  const uint32_t n_rounds = (n + 63u) >> 6;
-  const uint32_t n_iter = (n_rounds + RS_WAVES - 1) / RS_WAVES;
-  uint32_t r = (uint32_t)wave;
-  auto fetch = [&] (uint32_t round) -> uint64_t { const uint32_t i = round * 64u + (uint32_t)lane; return i < n ? Dc[i] : 0ull; };
-  auto is_valid = [&] (uint32_t round) -> bool { return round * 64u + (uint32_t)lane < n; };
-  // Decision words travel HBM -> LDS by LDS-DMA, three workgroup steps ahead of their use, so that neither the compiler's nor
-  // this code's waits for OTHER memory operations ever have to wait for a word that was only just requested.  (Always issued - the
-  // index is clamped - so that the counted wait below is right in the last steps too.)
-  const uint32_t my_ring = (uint32_t) (uintptr_t)&S.ring[wave][0][0][0];
-  auto dma = [&] (uint32_t round, uint32_t slot) {
-    uint32_t i = round * 64u + (uint32_t)lane;
-    if (i >= n) i = n - 1u;
-    const GLB uint32_t* src = (const GLB uint32_t*) (Dc + i);
+  const GLB uint64_t* Dg = glb<const uint64_t> (D);
+  for (int i = lane; i < R2_SLOTS; i += 64) S.ent[i] = 0ull;
+  if (lane == 0) S.nres = 0;
+  RoundGen G;
+  G.g = (uint32_t)uniform ((int)seg0[chain_first[chain]]); G.g_end = (uint32_t)uniform ((int)seg0[chain_first[chain + 1]]); G.part = part; G.pstride = (1u << log2p) + 1u;
+  G.dbase = (u64)I[LH264_CODER_INFO_DBASE] | (u64)I[LH264_CODER_INFO_DBASE + 1] << 32; G.cur = G.dbase; G.rem = 0;
+  if (G.g >= G.g_end) return;
+  G.request (seg_doff, seg_part);
+  wsync();
+  // Decision words travel HBM -> LDS by LDS-DMA, three rounds ahead of their use, so that neither the compiler's nor this code's
+  // waits for OTHER memory operations ever have to wait for a word that was only just requested.  (Always issued - a lane without a
+  // word reads the stream's first one - so that the counted wait below is right in the last rounds too.)
+  const uint32_t my_ring = (uint32_t) (uintptr_t)&S.ring[0][0][0];
+  auto dma = [&] (u64 idx, uint32_t slot) {
+    const GLB uint32_t* src = (const GLB uint32_t*) (Dg + idx);
     // (as asm statements: hipcc would make every later LDS read wait for a load it knows to write LDS; M0 = the LDS address of lane 0's
     // dword, saved and restored inside the statement)
     const uint32_t dst = (uint32_t)uniform ((int) (my_ring + slot * 512u));
@@ -663,78 +929,69 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
     asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
                   : "=&s"(keep) : "v"(src), "v"(src + 1), "s"(dst), "s"(dst + 256u) : "memory");
   };
-  if (n == 0u) return;
-  // rounds r (resolved in this step), r + W (looked up; a spilled answer is taken in this step), r + 2W (looked up in this step)
-  uint64_t w0 = fetch (r), w1 = fetch (r + RS_WAVES), w2 = fetch (r + 2 * RS_WAVES);
-  dma (r + 3 * RS_WAVES, 0u); dma (r + 4 * RS_WAVES, 1u); dma (r + 5 * RS_WAVES, 2u);
+  // rounds it (resolved in this iteration), it + 1 (looked up; a spilled answer is taken in this iteration), it + 2 (looked up in this
+  // iteration), it + 3 .. it + 2 + R2_DEPTH (under way into the ring)
+  u64 x0, x1, x2, xr;
+  uint32_t n0 = G.next (seg_doff, seg_part, lane, x0), n1 = G.next (seg_doff, seg_part, lane, x1), n2 = G.next (seg_doff, seg_part, lane, x2);
+  if (n0 == 0u) return;
+  uint64_t w0 = Dg[x0], w1 = Dg[x1], w2 = Dg[x2];
+  uint32_t nr[R2_DEPTH];                                   // words of the rounds in the ring (slot = round % R2_DEPTH)
+#pragma unroll
+  for (int k = 0; k < R2_DEPTH; k++) { nr[(3 + k) % R2_DEPTH] = G.next (seg_doff, seg_part, lane, xr); dma (xr, (uint32_t) ((3 + k) % R2_DEPTH)); }
+  // (once: the counted wait in the loop relies on what each iteration issues.  As the builtin, so that the compiler knows the three
+  // words loaded above have arrived: otherwise it puts "s_waitcnt vmcnt(0)" in front of their first use INSIDE the loop - the loop
+  // carries them - and every round drains the requests under way, i.e. waits for memory once per round)
+  __builtin_amdgcn_s_waitcnt (0x0F70);                     // vmcnt(0), gfx9 encoding
   bool spilled = false;
   SlotRef e0, e1;
-  rs_lookup (S, T, tmask, (uint32_t)w0, (uint32_t) (w0 >> 32), is_valid (r), false, e0);
-  rs_lookup (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), is_valid (r + RS_WAVES), false, e1);
-  rs_count (S, e0.inserted, lane); rs_count (S, e1.inserted, lane);
-  __syncthreads();
-  RS_STAMP_DECL
+  rs_lookup (S, T, tmask, (uint32_t)w0, (uint32_t) (w0 >> 32), (uint32_t)lane < n0, false, e0);
+  rs_lookup (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), (uint32_t)lane < n1, false, e1);
+  uint32_t nres = (uint32_t)__popcll (__ballot (e0.inserted)) + (uint32_t)__popcll (__ballot (e1.inserted));
   bool pend_ok = false; uint32_t pend_q = 0, pend_v = 0;
-  for (uint32_t it = 0; it < n_iter; it++) {
-    const bool v_cur = is_valid (r), round_ok = r < n_rounds;
-    // every RS_CHECK steps, and only while every wave of the step has a round
-    const bool check = (it % RS_CHECK) == RS_CHECK - 1 && (it + 1u) * RS_WAVES <= n_rounds;
-    bool do_flush = false;
-    if (pend_ok) Qc[pend_q] = (uint16_t)pend_v;          // the list entry of the round resolved in the last step
+  RS_STAMP_DECL
+  for (uint32_t it = 0; n0 != 0u; it++) {
+    const bool v_cur = (uint32_t)lane < n0;
+    if (pend_ok) Qc[pend_q] = (uint16_t)pend_v;          // the list entry of the round resolved in the last iteration
     pend_ok = false;
     const uint32_t w_hi = (uint32_t) (w0 >> 32);
-    // the words of round r + 3W: requested three steps ago; the four requests behind them may still be under way
-    asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
-    const uint32_t slot = it % 3u;
+    // the words of round it + 3: requested R2_DEPTH iterations ago.  Every iteration since has issued a store (the list entry) and two
+    // requests, this one a store: that many younger operations may still be under way
+    asm volatile ("s_waitcnt vmcnt(%0)" :: "n" (3 * (R2_DEPTH - 1) + 1) : "memory");
+    const uint32_t slot = (it + 3u) % R2_DEPTH;
     const uint64_t w3 = (uint64_t) * (volatile LDS uint32_t*) (uintptr_t) (my_ring + slot * 512u + (uint32_t)lane * 4u) |
                         (uint64_t) * (volatile LDS uint32_t*) (uintptr_t) (my_ring + slot * 512u + 256u + (uint32_t)lane * 4u) << 32;
-    RS_STAMP (5)
-    // ---- the entries of the round two steps ahead, first thing: spilled counters that are requested here are taken a whole step later
+    uint32_t n3 = 0;
+#pragma unroll
+    for (int k = 0; k < R2_DEPTH; k++) if (slot == (uint32_t)k) n3 = nr[k];
+    RS_STAMP (0)
+    // ---- the entries of the round two ahead, first thing: spilled counters that are requested here are taken a whole round later
     // (inserting does not disturb the rounds in flight: they use entries they found earlier) ----------------------------------------------
     SlotRef e2;
-    rs_lookup (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), is_valid (r + 2 * RS_WAVES), spilled, e2);
-    rs_count (S, e2.inserted, lane);
-    RS_STAMP (4)
-    // ---- what does not depend on the adaptive state: who shares my DynProb, who shares my tag ----------------------------------------
-    const bool raw = (w_hi & 0x80000000u) != 0;
-    const int bit = (int) ((w_hi >> 4) & 1u), tag = (int) ((w_hi >> 5) & 63u);
+    rs_lookup (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), (uint32_t)lane < n2, spilled, e2);
+    nres += (uint32_t)__popcll (__ballot (e2.inserted));
+    RS_STAMP (1)
+#ifdef LH264_CODER_DEBUG
+    { int mx = e2.iters; for (int m = 1; m < 64; m <<= 1) mx = max (mx, __shfl_xor (mx, m)); st_acc[9] += (unsigned long long)mx; }
+#endif
+    // ---- who shares my DynProb -----------------------------------------------------------------------------------------------------
+    const int bit = (int) ((w_hi >> 4) & 1u);
     const unsigned long long valid = __ballot (v_cur);
-    const uint32_t dkey = raw ? 0x3fffu : (uint32_t)e0.idx;                  // 13 bits of cache entry; 0x3fff: TEST_PROB
-    uint32_t slo, shi, tlo, thi;
-    wave_match<14> (dkey, valid, slo, shi);
-    wave_match<6> ((uint32_t)tag, valid, tlo, thi);
+    uint32_t slo, shi;
+    wave_match<R2_LOG2_BUCKETS + 2> ((uint32_t)e0.idx, valid, slo, shi);
     const unsigned long long zm = __ballot (v_cur && bit == 0);
     const int rank = below (slo, shi), nn = __popc (slo) + __popc (shi);
     const int z = below (slo & (uint32_t)zm, shi & (uint32_t) (zm >> 32));
-    const int trank = below (tlo, thi), tn = __popc (tlo) + __popc (thi);
     const int head = slo ? __ffs ((int)slo) - 1 : 32 + __ffs ((int)shi) - 1;
-    // spilled counters requested a step ago: into the entries now (before this wave's turn, see above)
+    // spilled counters requested a round ago: into the entries now
+    RS_STAMP (2)
     rs_land (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), e1);
-    RS_STAMP (0)
-    // ---- the serial section: counters in, counters out -------------------------------------------------------------------------------
-    if (round_ok) {
-      volatile LDS uint32_t* sp = raw ? &S.test_prob : (volatile LDS uint32_t*)&S.ent[e0.idx];
-      volatile LDS uint32_t* cp = &S.cursor[tag];
-      {   // (the spin is bounded so that a broken hand-off ends as a wrong result with a status bit, not as a hung GPU)
-        volatile LDS uint32_t* tk = &S.ticket;
-        uint32_t spins = 0;
-        // the wave that waits for the ticket is the stream's critical path: it polls at raised priority (measured: 5.8 -> 5.45 ms)
-        __builtin_amdgcn_s_setprio (2);
-        for (; *tk != r && spins < (1u << 20); spins++) { }
-        if (spins >= (1u << 20) && lane == 0) atomicOr (&chain_info[(size_t)chain * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_HANDOFF);
-      }
-      uint32_t st = 0, cb = 0;
-      if (v_cur) { st = *sp; cb = *cp; }
-      __builtin_amdgcn_s_setprio (3);                // the waves behind this one are waiting for exactly this section
+    RS_STAMP (3)
+    // ---- counters in, counters out -------------------------------------------------------------------------------------------------
+    {
+      volatile LDS uint32_t* sp = (volatile LDS uint32_t*)&S.ent[e0.idx] + 1;     // (the entry's high dword: place and counters)
+      uint32_t st = 0;
+      if (v_cur) st = *sp;
       asm volatile ("" ::: "memory");
-      RS_STAMP (1)
-      if (check) {
-        // is the cache filling up?  The first wave of the step decides inside its turn, the others read the decision inside theirs
-        // (later in ticket order): no barrier unless there is something to flush
-        volatile LDS uint32_t* fs = &S.flush_step;
-        if (wave == 0 && * (volatile LDS uint32_t*)&S.nres > RS_FLUSH) *fs = it;
-        do_flush = *fs == it;
-      }
       const uint32_t c0 = st & 1023u, c1 = (st >> 10) & 1023u;
       const bool lazy = c0 + c1 > 512u;                                     // the halving the last decision left to its successor
       const uint32_t f0 = lazy ? (c0 + 1u) >> 1 : c0, f1 = lazy ? (c1 + 1u) >> 1 : c1;
@@ -745,67 +1002,68 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
       if (__ballot (v_cur && nn > t + 1)) {
         // a halving inside the group: rank t + 1 is still coded from the pair as it stands after rank t, but counts on from the halved
         // pair, as do the ranks behind it
-        LDS uint32_t* sc = S.scratch[wave];
+        LDS uint32_t* sc = S.scratch;
         if (v_cur && rank == t + 1) sc[head] = (uint32_t)z;                 // zeros among ranks 0..t
-        __builtin_amdgcn_wave_barrier();
+        wsync();
         if (v_cur && rank > t) {
           const uint32_t zt = * (volatile LDS uint32_t*)&sc[head];
           const uint32_t h0 = (f0 + zt + 1u) >> 1, h1 = (f1 + (uint32_t) (t + 1) - zt + 1u) >> 1;
           b0 = h0 + ((uint32_t)z - zt); b1 = h1 + ((uint32_t) (rank - z) - ((uint32_t) (t + 1) - zt));
           if (rank > t + 1) { a0 = b0; a1 = b1; }
         }
-        __builtin_amdgcn_wave_barrier();
+        wsync();
       }
       if (v_cur && rank == nn - 1) *sp = (st & 0xfff00000u) | (b0 + (uint32_t) (bit ^ 1)) | (b1 + (uint32_t)bit) << 10;
-      if (v_cur && trank == tn - 1) *cp = cb + (uint32_t)tn;
       asm volatile ("" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) { volatile LDS uint32_t* tk = &S.ticket; *tk = r + 1u; }
-      __builtin_amdgcn_s_setprio (0);
-      RS_STAMP (2)
-      // ---- afterwards: the probability, and the entry of the tag's list ------------------------------------------------------------------
-      // (stored at the top of the next step: a store as the youngest memory operation at the loop's end would make the compiler's
-      // wait for the spill-table answers wait for the store as well)
-      // the list entry carries the probability of the bit that occurred (what the bool coder multiplies with, see bc_step)
+      // the list entry carries the probability of the bit that occurred (what the bool coder multiplies with, see code_step); stored at
+      // the top of the next iteration (a store as the youngest memory operation at the loop's end would make the compiler's wait for
+      // the spill-table answers wait for the store as well)
       const uint32_t prob = dp_ratio (a0, a1);
-      pend_ok = v_cur; pend_q = cb + (uint32_t)trank; pend_v = (bit ? 256u - prob : prob) << 1 | (uint32_t)bit;
+      pend_ok = v_cur; pend_q = w_hi >> 5; pend_v = (bit ? 256u - prob : prob) << 1 | (uint32_t)bit;
     }
-    RS_STAMP (3)
-    {
-      if (do_flush) {
-        // every DynProb to the spill table, then the cache starts over with the entries of the two rounds in flight
-        rs_land (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), e1);
-        rs_land (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), e2);
-        rs_barrier();
-        for (int i = tid; i < RS_SLOTS; i += RS_WAVES * 64) {
-          const unsigned long long e = S.ent[i];
-          if (e) {
-            if (!spill_put (T, tmask, RS_ENT_KEY (e), (uint32_t)e & 0xfffffu))
-              atomicOr (&chain_info[(size_t)chain * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_TABLE_FULL);
-            S.ent[i] = 0ull;
-          }
-        }
-        if (tid == 0) S.nres = 0;
-        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-        rs_barrier();
-        spilled = true;
-        rs_lookup (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), is_valid (r + RS_WAVES), true, e1);
-        rs_lookup (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), is_valid (r + 2 * RS_WAVES), true, e2);
-        rs_count (S, e1.inserted, lane); rs_count (S, e2.inserted, lane);
-        rs_land (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), e1);
-        rs_land (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), e2);
-        rs_barrier();
-      }
+    RS_STAMP (4)
+    if ((it % R2_CHECK) == R2_CHECK - 1 && nres > R2_FLUSH) {
+      // every DynProb to the spill table, then the cache starts over with the entries of the two rounds in flight
+      rs_land (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), e1);
+      rs_land (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), e2);
+      wsync();
+      if (!rs_flush (S, T, tmask, lane)) atomicOr (&I[LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_TABLE_FULL);
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+      wsync();
+#ifdef LH264_CODER_DEBUG
+      st_acc[8] += 1;
+#endif
+      spilled = true;
+      rs_lookup (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), (uint32_t)lane < n1, true, e1);
+      rs_lookup (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), (uint32_t)lane < n2, true, e2);
+      nres = (uint32_t)__popcll (__ballot (e1.inserted)) + (uint32_t)__popcll (__ballot (e2.inserted));
+      rs_land (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), e1);
+      rs_land (S, T, tmask, (uint32_t)w2, (uint32_t) (w2 >> 32), e2);
+      wsync();
     }
-    asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ring slot has been read: it takes the words of round r + 6W
-    dma (r + 6 * RS_WAVES, slot);
-    r += RS_WAVES;
-    w0 = w1; w1 = w2; w2 = is_valid (r + 2 * RS_WAVES) ? w3 : 0ull;
+    RS_STAMP (5)
+    asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ring slot has been read: it takes the words of round it + 3 + R2_DEPTH
+    const uint32_t nn6 = G.next (seg_doff, seg_part, lane, xr);
+    dma (xr, slot);
+#pragma unroll
+    for (int k = 0; k < R2_DEPTH; k++) if (slot == (uint32_t)k) nr[k] = nn6;
+    w0 = w1; w1 = w2; w2 = w3;
+    n0 = n1; n1 = n2; n2 = n3;
     e0 = e1; e1 = e2;
+    RS_STAMP (6)
+#ifdef LH264_CODER_DEBUG
+    st_acc[7] += 1;
+#endif
   }
   if (pend_ok) Qc[pend_q] = (uint16_t)pend_v;
   RS_STAMP_FLUSH
 }
+#ifdef LH264_CODER_DEBUG
+void read_rs_stamps (unsigned long long* out, bool reset) {
+  (void)hipMemcpyFromSymbol (out, HIP_SYMBOL (g_rs_stamps), sizeof (g_rs_stamps));
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol (HIP_SYMBOL (g_rs_stamps), z, sizeof (z)); }
+}
+#endif
 
 // ---- kernels 6..9: the libvpx bool coder (vpx_writer, bitwriter.h:35-105; vpx_stop_encode bitwriter.cpp:17-37) ----------------
 // vpx_write keeps (low, range, count).  `range` depends only on the decisions so far - a 7-bit state that does not forget where it
@@ -825,6 +1083,7 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
 // r = rq >> 8, and the normalising shift (vpx_norm[r]) is the number of leading zeros of rq << 16.
 #define CODE_CHUNK ((uint32_t)LH264_CODER_CODE_CHUNK)
 #define CODE_STOP_ENTRY (128u << 1)
+#define CODE_COARSE ((uint32_t)LH264_CODER_CODE_COARSE)      // decisions per coarse chunk of the range walk (a multiple of CODE_CHUNK)
 struct CodeStep { uint32_t add, shift; };
 __device__ __forceinline__ CodeStep code_step (uint32_t& range, uint32_t e) {
   const uint32_t q = (e >> 1) & 0x1ffu;
@@ -867,39 +1126,53 @@ __device__ __forceinline__ PairInfo pair_info (const uint32_t* chain_info, const
 
 // kernel 6: chunks per (stream, tag) pair and their running sum (one workgroup)
 __global__ void __launch_bounds__ (1024)
-coder_chunkmap_kernel (const uint32_t* __restrict__ chain_info, int n_pairs, uint32_t* __restrict__ pair_chunk0) {
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t carry;
+coder_chunkmap_kernel (const uint32_t* __restrict__ chain_info, int n_pairs, uint32_t* __restrict__ pair_chunk0, uint32_t* __restrict__ pair_coarse0) {
+  __shared__ uint32_t wsum[16], wsum2[16];
+  __shared__ uint32_t carry, carry2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0;
+  if (tid == 0) { carry = 0; carry2 = 0; }
   __syncthreads();
   for (int p0 = 0; p0 < n_pairs; p0 += 1024) {
     const int p = p0 + tid;
-    uint32_t v = 0;
+    uint32_t v = 0, v2 = 0;
     if (p < n_pairs) {
       const uint32_t chain = (uint32_t)p / LH264_N_TAG_SLOTS, slot = (uint32_t)p % LH264_N_TAG_SLOTS;
       const uint32_t* I = chain_info + (size_t)chain * LH264_CODER_INFO_WORDS;
       const uint32_t n = slot < 35u ? I[LH264_CODER_INFO_TAGCNT + slot] : 0u;
       const unsigned long long tm = (unsigned long long)I[LH264_CODER_INFO_TOUCH] | (unsigned long long)I[LH264_CODER_INFO_TOUCH + 1] << 32;
-      if (slot < 35u && (n > 0u || ((tm >> slot) & 1ull))) v = (n + 32u + CODE_CHUNK - 1u) / CODE_CHUNK;
+      if (slot < 35u && (n > 0u || ((tm >> slot) & 1ull))) { v = (n + 32u + CODE_CHUNK - 1u) / CODE_CHUNK; v2 = (n + 32u + CODE_COARSE - 1u) / CODE_COARSE; }
     }
-    const uint32_t incl = (uint32_t)wave_scan_add ((int)v);
-    if (lane == 63) wsum[wave] = incl;
+    const uint32_t incl = (uint32_t)wave_scan_add ((int)v), incl2 = (uint32_t)wave_scan_add ((int)v2);
+    if (lane == 63) { wsum[wave] = incl; wsum2[wave] = incl2; }
     __syncthreads();
-    uint32_t before = carry;
-    for (int w = 0; w < wave; w++) before += wsum[w];
-    if (p < n_pairs) pair_chunk0[p] = before + incl - v;
+    uint32_t before = carry, before2 = carry2;
+    for (int w = 0; w < wave; w++) { before += wsum[w]; before2 += wsum2[w]; }
+    if (p < n_pairs) { pair_chunk0[p] = before + incl - v; pair_coarse0[p] = before2 + incl2 - v2; }
     __syncthreads();
-    if (tid == 1023) carry = before + incl;
+    if (tid == 1023) { carry = before + incl; carry2 = before2 + incl2; }
     __syncthreads();
   }
-  if (tid == 0) pair_chunk0[n_pairs] = carry;
+  if (tid == 0) { pair_chunk0[n_pairs] = carry; pair_coarse0[n_pairs] = carry2; }
 }
 
-// kernel 7: per pair, the range recurrence over the whole list; per chunk {range | pair << 8, bits shifted out} at its first decision.
-// A wave = one tag slot of 64 consecutive streams: lists of about the same length in its lanes.  (Two lists per lane, their steps
-// interleaved in one instruction stream, were slower - 4.2 vs 3.1 ms: a lone wave is bound by the number of instructions it issues,
-// not by the latency of the recurrence.)
+// kernel 7: the range recurrence, cut into coarse chunks of CODE_COARSE decisions so that a long list is walked by many lanes.
+// `range` is a 7-bit state (128..255 after every decision) that does not forget its start - two start values stay apart for thousands
+// of decisions - but every decision that shifts bits out merges states, and after 1,024 decisions at most 4 of the 128 possible states
+// are left in 90 % of all cases, at most 8 in 96 % (measured on the bench streams, tools/range_probe.py; the rest are lists that
+// only rotate the states, e.g. a constant run at probability 255).  So:
+//   coder_range_seed_kernel   one wave per coarse chunk: walks the CODE_LOOKBACK decisions in front of the chunk from ALL 128 states
+//                             (two per lane; the decision is wave-uniform) and notes the states that are left - the CANDIDATES for the
+//                             chunk's start state, at most 8; a chunk with more is left "unresolved".  Chunk 0 of a list starts at 255.
+//   coder_range_cand_kernel   one lane per (coarse chunk, candidate): the recurrence from the candidate over the chunk (and on through
+//                             unresolved chunks behind it) -> the state at the start of the next resolved chunk, IF the chunk starts there
+//   coder_range_link_kernel   one lane per pair: from 255 at the list's start, chunk after chunk: which candidate is the true start state,
+//                             what that makes the next chunk's
+//   coder_range_walk_kernel   one lane per resolved coarse chunk: the recurrence from the true start state, noting {range | pair << 8,
+//                             bits shifted out since the coarse chunk's start} at every chunk of CODE_CHUNK decisions, and the bits each
+//                             coarse chunk shifts out
+//   coder_range_scan_kernel   one wave per pair: running sum of those bits over the pair's coarse chunks
+// Worst case (a list whose states never merge): one lane walks the whole list, as the one-lane-per-pair kernel of round 2 did for
+// every list (178 ms for the 1080p batch).
 // Loads the compiler does not know about: a loop that reads ahead through ordinary loads gets "s_waitcnt vmcnt(0)" at its head
 // (the loop-carried loads are tracked conservatively), i.e. one memory round trip per iteration.  Here the load and the wait are
 // written out: `code_ld16` starts a 16-byte load into v (tied: the register is not renamed, nothing copies it while the data is
@@ -907,9 +1180,58 @@ coder_chunkmap_kernel (const uint32_t* __restrict__ chain_info, int n_pairs, uin
 __device__ __forceinline__ void code_ld16 (u32x4& v, const GLB u32x4* p) { asm volatile ("global_load_dwordx4 %0, %1, off" : "+v" (v) : "v" (p) : "memory"); }
 template <int N> __device__ __forceinline__ void code_wait (u32x4& v) { asm volatile ("s_waitcnt vmcnt(%1)" : "+v" (v) : "n" (N) : "memory"); }
 
+// which pair coarse chunk G belongs to: the largest p with pair_coarse0[p] <= G (pairs without chunks share their successor's start)
+__device__ __forceinline__ uint32_t coarse_pair (const uint32_t* __restrict__ pair_coarse0, uint32_t n_pairs, uint32_t G) {
+  uint32_t lo = 0, hi = n_pairs;
+  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (pair_coarse0[mid] <= G) lo = mid; else hi = mid; }
+  return lo;
+}
+
+#define CODE_LOOKBACK 1024u
+#define CODE_CANDS 8
+__global__ void __launch_bounds__ (256)
+coder_range_seed_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_coarse0, int n_pairs,
+                         uint32_t* __restrict__ cand) {
+  const uint32_t G = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (G >= pair_coarse0[n_pairs]) return;
+  const uint32_t pair = (uint32_t)uniform ((int)coarse_pair (pair_coarse0, (uint32_t)n_pairs, G));
+  const uint32_t c = G - pair_coarse0[pair];
+  if (c == 0u) { if (lane < 2u) cand[2 * (size_t)G + lane] = lane == 0u ? 255u : 0u; return; }
+  const PairInfo P = pair_info (chain_info, Q, pair);
+  const uint32_t b = c * CODE_COARSE;
+  uint32_t r0 = 128u + lane, r1 = 192u + lane;
+  for (uint32_t i0 = b - CODE_LOOKBACK; i0 < b; i0 += 64u) {
+    const uint32_t idx = i0 + lane;
+    const uint32_t e = idx < P.n ? (uint32_t)P.list[idx] : CODE_STOP_ENTRY;
+#pragma unroll 8
+    for (int i = 0; i < 64; i++) {
+      const uint32_t ei = (uint32_t)__builtin_amdgcn_readlane ((int)e, i);
+      const uint32_t q = (ei >> 1) & 0x1ffu, k = 256u - (ei & 1u) - q;
+      const uint32_t a0 = r0 * q + k, a1 = r1 * q + k;
+      r0 = (a0 >> 8) << __builtin_clz (a0 << 16);
+      r1 = (a1 >> 8) << __builtin_clz (a1 << 16);
+    }
+  }
+  // the states that are left, one after the other (8 bytes; 0: none - a state is at least 128)
+  bool act0 = true, act1 = true;
+  unsigned long long cs = 0;
+  for (int k = 0; k < CODE_CANDS; k++) {
+    const unsigned long long m0 = __ballot (act0), m1 = __ballot (act1);
+    if ((m0 | m1) == 0ull) break;
+    const uint32_t v = m0 ? (uint32_t)__builtin_amdgcn_readlane ((int)r0, (int)__ffsll ((long long)m0) - 1) : (uint32_t)__builtin_amdgcn_readlane ((int)r1, (int)__ffsll ((long long)m1) - 1);
+    cs |= (unsigned long long)v << (8 * k);
+    act0 = act0 && r0 != v; act1 = act1 && r1 != v;
+  }
+  if (__ballot (act0 || act1)) cs = 0;                 // more than CODE_CANDS states left: unresolved
+#ifdef LH264_RANGE_PROBE     // diagnostic build: how many distinct states are left, noted behind the candidates
+  { uint32_t d = 0; for (uint32_t v = 128u; v < 256u; v++) d += __ballot (r0 == v || r1 == v) != 0ull; if (lane == 0u) cand[2 * (size_t)pair_coarse0[n_pairs] + G] = d; }
+#endif
+  if (lane < 2u) cand[2 * (size_t)G + lane] = (uint32_t) (cs >> (32 * lane));
+}
+
 struct RangeWalk {
   GLB uint32_t* rec; uint32_t range, pos, g0, pair;
-  __device__ __forceinline__ void note (uint32_t i) { const size_t g = g0 + i / CODE_CHUNK; rec[2 * g] = range | pair << 8; rec[2 * g + 1] = pos; }
+  __device__ __forceinline__ void note (uint32_t i) { if (rec) { const size_t g = g0 + i / CODE_CHUNK; rec[2 * g] = range | pair << 8; rec[2 * g + 1] = pos; } }
   // one whole piece (8 decisions): no test per decision; a chunk starts on a piece
   __device__ __forceinline__ void piece (const u32x4 v, uint32_t c) {
     if ((c & (CODE_CHUNK / 8 - 1u)) == 0u) note (c * 8u);
@@ -919,24 +1241,32 @@ struct RangeWalk {
   }
 };
 #define CODE_AHEAD 8u        // 16-byte pieces of the list under way per lane
-__global__ void __launch_bounds__ (64)
-coder_range_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0, int n_chains,
-                    int groups, uint32_t* __restrict__ chunk_rec, uint32_t* __restrict__ pair_bits) {
-  const uint32_t slot = blockIdx.x / (uint32_t)groups, chain = (blockIdx.x % (uint32_t)groups) * 64u + threadIdx.x;
-  if (chain >= (uint32_t)n_chains) return;
+// the walk of coarse chunk G from state s0, on through the unresolved chunks behind it.  NOTES: the final walk (chunk_rec, coarse_bits);
+// otherwise only the state the walk ends with is wanted.  resolved[2 * G] != 0 <=> chunk G has candidates (a lane of its own).
+template <bool NOTES>
+__device__ __forceinline__ uint32_t range_walk (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0,
+                                                const uint32_t* __restrict__ pair_coarse0, int n_pairs, const uint32_t* __restrict__ resolved,
+                                                uint32_t G, uint32_t s0, uint32_t* __restrict__ chunk_rec, uint32_t* __restrict__ coarse_bits) {
   RangeWalk A;
-  A.pair = chain * LH264_N_TAG_SLOTS + slot; A.range = 255u; A.pos = 0; A.rec = glb<uint32_t> (chunk_rec);
+  A.pair = coarse_pair (pair_coarse0, (uint32_t)n_pairs, G);
+  A.range = s0; A.pos = 0; A.rec = NOTES ? glb<uint32_t> (chunk_rec) : (GLB uint32_t*)nullptr;
   A.g0 = pair_chunk0[A.pair];
-  if (pair_chunk0[A.pair + 1] != A.g0) {
-    const PairInfo P = pair_info (chain_info, Q, A.pair);
-    const uint32_t n = P.n, pieces = (n + 7u) >> 3, whole = n >> 3, last = pieces ? pieces - 1u : 0u;
-    const GLB u32x4* src = (const GLB u32x4*)P.list;
+  const uint32_t G_end = pair_coarse0[A.pair + 1];
+  const PairInfo P = pair_info (chain_info, Q, A.pair);
+  const uint32_t n = P.n;
+  const GLB u32x4* src = (const GLB u32x4*)P.list;
+  for (uint32_t cc = G - pair_coarse0[A.pair]; ; cc++, G++) {
+    // decisions [i0, i1) of the list (the 32 stop decisions lie behind the n real ones); pieces [c, whole) are whole and real
+    const uint32_t i0 = cc * CODE_COARSE, i1 = min (i0 + CODE_COARSE, P.total);
+    const uint32_t whole = min (i1, n) >> 3, last = n ? ((n + 7u) >> 3) - 1u : 0u;
+    uint32_t c = i0 >> 3;
+    A.pos = 0;
     // eight separate registers quadruples (an array would be one aggregate that the compiler copies around while loads are under way)
     u32x4 b0 = {0u, 0u, 0u, 0u}, b1 = b0, b2 = b0, b3 = b0, b4 = b0, b5 = b0, b6 = b0, b7 = b0;
-#define CODE_FIRST(B, J) if (pieces) code_ld16 (B, src + min ((uint32_t) (J), last));
+    const bool any = c < whole || (whole << 3) < min (i1, n);      // the chunk reads the list at all
+#define CODE_FIRST(B, J) if (any) code_ld16 (B, src + min (c + (uint32_t) (J), last));
     CODE_FIRST (b0, 0) CODE_FIRST (b1, 1) CODE_FIRST (b2, 2) CODE_FIRST (b3, 3) CODE_FIRST (b4, 4) CODE_FIRST (b5, 5) CODE_FIRST (b6, 6) CODE_FIRST (b7, 7)
 #undef CODE_FIRST
-    uint32_t c = 0;
     // CODE_AHEAD loads are under way all the time (behind the end of the list the last piece is read again), so the oldest one has
     // arrived when at most CODE_AHEAD - 1 are outstanding
 #define CODE_TURN(B, J) code_wait<CODE_AHEAD - 1> (B); A.piece (B, c + (J)); code_ld16 (B, src + min (c + (J) + CODE_AHEAD, last));
@@ -945,29 +1275,102 @@ coder_range_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __r
     }
 #undef CODE_TURN
     code_wait<0> (b0); code_wait<0> (b1); code_wait<0> (b2); code_wait<0> (b3); code_wait<0> (b4); code_wait<0> (b5); code_wait<0> (b6); code_wait<0> (b7);
-    // fewer than CODE_AHEAD whole pieces are left: register j holds piece min (c + j, last); then the last, partial piece
-    const uint32_t left = whole - c;
+    // fewer than CODE_AHEAD whole pieces are left: register j holds piece min (c + j, last); then the list's last, partial piece
+    const uint32_t left = c < whole ? whole - c : 0u;
     u32x4 pv = b0;
 #define CODE_LAST(B, J) if ((J) < left) A.piece (B, c + (J)); if (left == (J)) pv = B;
     CODE_LAST (b0, 0u) CODE_LAST (b1, 1u) CODE_LAST (b2, 2u) CODE_LAST (b3, 3u) CODE_LAST (b4, 4u) CODE_LAST (b5, 5u) CODE_LAST (b6, 6u) CODE_LAST (b7, 7u)
 #undef CODE_LAST
     const uint32_t w[4] = {pv.x, pv.y, pv.z, pv.w};
-    for (uint32_t i = whole * 8u; i < P.total; i++) {
+    for (uint32_t i = max (i0, whole * 8u); i < i1; i++) {
       if ((i & (CODE_CHUNK - 1u)) == 0u) A.note (i);
       const uint32_t j = i & 7u;
       const uint32_t wj = (j & 4u) ? ((j & 2u) ? w[3] : w[2]) : ((j & 2u) ? w[1] : w[0]);
       A.pos += code_step (A.range, i < n ? wj >> (16u * (j & 1u)) : CODE_STOP_ENTRY).shift;
     }
+    if (NOTES) coarse_bits[G] = A.pos;                  // the bits this coarse chunk shifts out
+    if (G + 1u >= G_end || resolved[2 * (size_t) (G + 1u)] != 0u) break;   // the next chunk has a lane of its own (or there is none)
   }
-  pair_bits[A.pair] = A.pos;                            // all the bits the list shifts out
+  return A.range;
+}
+// one lane per coarse chunk with ONE candidate (every list's first chunk is one): that is its start state - the final walk at once
+__global__ void __launch_bounds__ (64)
+coder_range_walk1_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0,
+                          const uint32_t* __restrict__ pair_coarse0, int n_pairs, const uint32_t* __restrict__ cand, uint8_t* __restrict__ cand_end,
+                          uint32_t* __restrict__ chunk_rec, uint32_t* __restrict__ coarse_bits) {
+  const uint32_t G = blockIdx.x * 64u + threadIdx.x;
+  if (G >= pair_coarse0[n_pairs]) return;
+  const uint32_t c0 = cand[2 * (size_t)G], c1 = cand[2 * (size_t)G + 1];
+  if (c0 == 0u || (c0 >> 8) != 0u || c1 != 0u) return;
+  cand_end[(size_t)G * CODE_CANDS] = (uint8_t)range_walk<true> (chain_info, Q, pair_chunk0, pair_coarse0, n_pairs, cand, G, c0, chunk_rec, coarse_bits);
+}
+// one lane per (coarse chunk with several candidates, candidate start state): where the walk ends
+__global__ void __launch_bounds__ (64)
+coder_range_cand_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0,
+                         const uint32_t* __restrict__ pair_coarse0, int n_pairs, const uint32_t* __restrict__ cand, uint8_t* __restrict__ cand_end) {
+  const uint32_t G = blockIdx.x * (64u / CODE_CANDS) + threadIdx.x / CODE_CANDS, k = threadIdx.x % CODE_CANDS;
+  if (G >= pair_coarse0[n_pairs]) return;
+  const uint32_t c0 = cand[2 * (size_t)G], c1 = cand[2 * (size_t)G + 1];
+  if ((c0 >> 8) == 0u && c1 == 0u) return;              // none (unresolved) or one (walked by coder_range_walk1_kernel)
+  const uint32_t s0 = ((k < 4u ? c0 : c1) >> (8 * (k & 3))) & 0xffu;
+  if (s0 == 0u) return;
+  cand_end[(size_t)G * CODE_CANDS + k] = (uint8_t)range_walk<false> (chain_info, Q, pair_chunk0, pair_coarse0, n_pairs, cand, G, s0, nullptr, nullptr);
+}
+// one lane per pair: the true start state of every coarse chunk with several candidates (seed; 0 for the others: walked already, or
+// walked by the lane of the chunk in front of them)
+__global__ void __launch_bounds__ (64)
+coder_range_link_kernel (const uint32_t* __restrict__ pair_coarse0, int n_pairs, const uint32_t* __restrict__ cand, const uint8_t* __restrict__ cand_end,
+                         uint32_t* __restrict__ seed, uint32_t* __restrict__ chain_info) {
+  const uint32_t pair = blockIdx.x * 64u + threadIdx.x;
+  if (pair >= (uint32_t)n_pairs) return;
+  uint32_t s = 255u;
+  bool lost = false;
+  for (uint32_t G = pair_coarse0[pair]; G < pair_coarse0[pair + 1]; G++) {
+    const unsigned long long cs = (unsigned long long)cand[2 * (size_t)G] | (unsigned long long)cand[2 * (size_t)G + 1] << 32;
+    if (cs == 0ull) { seed[G] = 0u; continue; }
+    int k = -1;
+    for (int q = CODE_CANDS - 1; q >= 0; q--) if (((cs >> (8 * q)) & 0xffull) == (unsigned long long)s) k = q;
+    if (k < 0) { lost = true; k = 0; }                 // (cannot happen: the lookback starts from every state)
+    seed[G] = (cs >> 8) == 0ull ? 0u : s;
+    s = cand_end[(size_t)G * CODE_CANDS + k];
+  }
+  if (lost) atomicOr (&chain_info[(size_t) (pair / LH264_N_TAG_SLOTS) * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS], (uint32_t)LH264_CODER_ST_HANDOFF);
+}
+__global__ void __launch_bounds__ (64)
+coder_range_walk_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0,
+                         const uint32_t* __restrict__ pair_coarse0, int n_pairs, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ seed,
+                         uint32_t* __restrict__ chunk_rec, uint32_t* __restrict__ coarse_bits) {
+  const uint32_t G = blockIdx.x * 64u + threadIdx.x;
+  if (G >= pair_coarse0[n_pairs]) return;
+  const uint32_t s0 = seed[G];
+  if (s0 == 0u) return;                                 // walked by the lane of the resolved chunk in front of it
+  range_walk<true> (chain_info, Q, pair_chunk0, pair_coarse0, n_pairs, cand, G, s0, chunk_rec, coarse_bits);
+}
+
+// running sum of the bits over a pair's coarse chunks: coarse_bits[G] becomes the bits shifted out in front of coarse chunk G,
+// pair_bits[pair] all the bits the list shifts out
+__global__ void __launch_bounds__ (256)
+coder_range_scan_kernel (const uint32_t* __restrict__ pair_coarse0, int n_pairs, uint32_t* __restrict__ coarse_bits, uint32_t* __restrict__ pair_bits) {
+  const uint32_t pair = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (pair >= (uint32_t)n_pairs) return;
+  const uint32_t G0 = pair_coarse0[pair], G1 = pair_coarse0[pair + 1];
+  uint32_t carry = 0;
+  for (uint32_t g = G0; g < G1; g += 64u) {
+    const uint32_t v = g + lane < G1 ? coarse_bits[g + lane] : 0u;
+    const uint32_t incl = (uint32_t)wave_scan_add ((int)v);
+    if (g + lane < G1) coarse_bits[g + lane] = carry + incl - v;
+    carry += (uint32_t)__builtin_amdgcn_readlane ((int)incl, 63);
+  }
+  if (lane == 0u) pair_bits[pair] = carry;
 }
 
 // kernel 8: the addends of every chunk into the sums of the output byte positions.  A position takes addends from the decisions that
 // start in its byte or in the byte before; the positions strictly inside a chunk's span of bits belong to that chunk alone and are
 // stored, the two at either end are shared with the neighbouring chunks and added atomically (the sums start out as zero).
 __global__ void __launch_bounds__ (256)
-coder_accum_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0, int n_pairs,
-                    const uint32_t* __restrict__ chunk_rec, const uint32_t* __restrict__ pair_bits, uint32_t* __restrict__ acc) {
+coder_accum_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0,
+                    const uint32_t* __restrict__ pair_coarse0, int n_pairs,
+                    const uint32_t* __restrict__ chunk_rec, const uint32_t* __restrict__ coarse_bits, const uint32_t* __restrict__ pair_bits, uint32_t* __restrict__ acc) {
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
   if (g >= pair_chunk0[n_pairs]) return;
   uint32_t range = chunk_rec[2 * (size_t)g], t = chunk_rec[2 * (size_t)g + 1];
@@ -975,7 +1378,11 @@ coder_accum_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __r
   range &= 0xffu;
   const PairInfo P = pair_info (chain_info, Q, pair);
   const uint32_t c = g - pair_chunk0[pair], i0 = c * CODE_CHUNK, i1 = min (i0 + CODE_CHUNK, P.total);
-  const uint32_t t_end = g + 1u < pair_chunk0[pair + 1] ? chunk_rec[2 * (size_t)g + 3] : pair_bits[pair];     // where the next chunk starts
+  // (the noted bit positions count from the start of the coarse chunk: the bits in front of it on top)
+  const uint32_t G0 = pair_coarse0[pair];
+  t += coarse_bits[G0 + c / (CODE_COARSE / CODE_CHUNK)];
+  const uint32_t t_end = g + 1u < pair_chunk0[pair + 1] ? chunk_rec[2 * (size_t)g + 3] + coarse_bits[G0 + (c + 1u) / (CODE_COARSE / CODE_CHUNK)]
+                                                        : pair_bits[pair];     // where the next chunk starts
   const uint32_t own_lo = (t >> 3) + 2u, own_hi = t_end >> 3;            // positions own_lo .. own_hi - 1 are this chunk's alone
   GLB uint32_t* A = glb<uint32_t> (acc) + P.acc0;
   auto put = [&] (uint32_t kpos, uint32_t v) {

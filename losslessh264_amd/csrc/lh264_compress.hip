@@ -300,6 +300,7 @@ int lh264_compress_batch (const uint8_t* const* data, const size_t* len, int n, 
       for (auto& f : P.frames()) { mbs += (size_t)f->mb_w * f->mb_h; symbols = symbols && f->syn_off.size() == (size_t)f->mb_w * f->mb_h + 1 && (f->syn_off.back() == f->syn_syms.size()); }
       if (!P.error().empty()) { r.status = LH264_E_UNSUPPORTED; r.error = P.error(); }
       else if (!symbols) { r.status = LH264_E_UNSUPPORTED; r.error = "a picture with an incomplete slice"; }
+      else if (P.damaged()) { r.status = LH264_E_UNSUPPORTED; r.error = "a picture with macroblocks no slice covers: the reference conceals them, which is not modelled (the stream would not restore)"; }
       if (r.status != LH264_OK || mbs == 0) { parsers[i].reset(); continue; }
       if (in_group && in_group + mbs > kBudget) { launch (group); in_group = 0; }
       group.push_back (i); in_group += mbs;

@@ -389,33 +389,37 @@ __device__ __forceinline__ int pred4_dir (const LDS uint8_t* T, int bx, int by, 
   return (e0 + e1 + 1) >> 1;
 }
 
-// RecI4x4Luma rec_mb.cpp:124-157: 16 blocks in z-order, one lane per sample
+// RecI4x4Luma rec_mb.cpp:124-157, one lane per sample.  The reference walks the 16 blocks in z-order; a block reads its left, top,
+// top-left and - where H.264 calls it available, i.e. where it comes earlier in z-order - top-right neighbour block.  All of those have a
+// smaller bx + 2 by, so the blocks of one anti-diagonal bx + 2 by = t are independent of each other: 10 steps of one or two blocks (lanes
+// 0..15 and 16..31) instead of 16 steps of one.  (A block whose top-right neighbour is NOT available was given a *_TOP mode by the
+// parser, parse_mb_syn_cavlc.cpp:519-611, and does not look at it - that it may already be there in this order does not matter.)
 __device__ LH264_PHASE void intra4x4_phase (LDS WaveLds& L, RecView m, int lane) {
   LDS uint8_t* T = L.T;
-  for (int blk = 0; blk < 16; blk++) {
-    const int qx = (blk & 1) | ((blk >> 2) & 1) << 1, qy = ((blk >> 1) & 1) | ((blk >> 3) & 1) << 1;
-    const int mode = uni (m.intra_mode (qy * 4 + qx));
-    if (lane < 16) {
-      const int x = lane & 3, y = lane >> 2;
+  const int half = (lane >> 4) & 1, x = lane & 3, y = (lane >> 2) & 3;
+  for (int t = 0; t < 10; t++) {
+    // blocks on this anti-diagonal: by from max (0, ceil ((t - 3) / 2)) to min (3, t / 2); at most two
+    const int by0 = t <= 3 ? 0 : (t - 2) >> 1;
+    const int by1 = min (3, t >> 1);
+    const int qy = by0 + half, qx = t - 2 * qy;
+    const bool act = lane < 32 && qy <= by1 && qx >= 0 && qx <= 3;
+    if (act) {
+      const int mode = m.intra_mode (qy * 4 + qx);
       int v;
-      switch (mode) {
-      case LH264_I4_V: v = T[tY (4 * qy - 1, 4 * qx + x)]; break;
-      case LH264_I4_H: v = T[tY (4 * qy + y, 4 * qx - 1)]; break;
-      case LH264_I4_DC: case LH264_I4_DC_L: case LH264_I4_DC_T: {
+      if (mode == LH264_I4_V) v = T[tY (4 * qy - 1, 4 * qx + x)];
+      else if (mode == LH264_I4_H) v = T[tY (4 * qy + y, 4 * qx - 1)];
+      else if (mode == LH264_I4_DC || mode == LH264_I4_DC_L || mode == LH264_I4_DC_T) {
         int s = 0;
         if (mode != LH264_I4_DC_L) {
-          const uint32_t t = * (const LDS uint32_t*)&T[tY (4 * qy - 1, 4 * qx)];
-          s += (t & 0xff) + ((t >> 8) & 0xff) + ((t >> 16) & 0xff) + (t >> 24);
+          const uint32_t tw = * (const LDS uint32_t*)&T[tY (4 * qy - 1, 4 * qx)];
+          s += (tw & 0xff) + ((tw >> 8) & 0xff) + ((tw >> 16) & 0xff) + (tw >> 24);
         }
         if (mode != LH264_I4_DC_T)
           s += (int)T[tY (4 * qy, 4 * qx - 1)] + (int)T[tY (4 * qy + 1, 4 * qx - 1)] + (int)T[tY (4 * qy + 2, 4 * qx - 1)] + (int)T[tY (4 * qy + 3, 4 * qx - 1)];
         v = (mode == LH264_I4_DC) ? (s + 4) >> 3 : (s + 2) >> 2;
-        break;
-      }
-      case LH264_I4_DC_128: v = 128; break;
-      default: v = pred4_dir (T, qx, qy, mode, x, y); break;
-      }
-      const int rr = L.R[blk * 16 + y * 4 + x];
+      } else if (mode == LH264_I4_DC_128) v = 128;
+      else v = pred4_dir (T, qx, qy, mode, x, y);
+      const int rr = L.R[zidx (qx, qy) * 16 + y * 4 + x];
       T[tY (4 * qy + y, 4 * qx + x)] = (uint8_t)clip_u8 (v + rr);
     }
     wsync();

@@ -140,6 +140,38 @@ def test_coder_in_two_calls_equals_one_call():
         coder.finish()
 
 
+def test_coder_calls_on_two_hip_streams_do_not_share_work_memory_at_the_same_time():
+    """the coder's work memory (decision words, tag lists, sums) is one set per device: a call on another HIP stream must wait on the
+    device for the call before it (an event), not only for the host-side lock - otherwise the second call's binarisation overwrites
+    what the first call's kernels are still reading"""
+    import torch
+    import losslessh264_amd as lh
+    names = ["SVA_BA1_B.264", "test_qcif_cabac.264"]
+    streams = [lh.parse_file(open(os.path.join(golden_io.GOLDEN_DIR, "streams", n), "rb").read())[0] for n in names]
+    a_ctx = lh.CtxSession(streams, replicate=40)                  # long enough to be still running when the second call arrives
+    b_ctx = lh.CtxSession(streams[::-1], replicate=2)
+    a_ctx.run(); b_ctx.run()
+    a, b = lh.CoderSession(a_ctx), lh.CoderSession(b_ctx)
+    a.run(); b.run()
+    torch.cuda.synchronize(a_ctx.dev)
+    want_a, want_b = [a.tags(c) for c in range(80)], [b.tags(c) for c in range(4)]
+    s1, s2 = torch.cuda.Stream(a_ctx.dev), torch.cuda.Stream(a_ctx.dev)
+    for _ in range(3):
+        a.d_out.zero_(); b.d_out.zero_()
+        torch.cuda.synchronize(a_ctx.dev)
+        with torch.cuda.stream(s1):
+            a.run()
+        with torch.cuda.stream(s2):
+            b.run()
+        with torch.cuda.stream(s1):
+            a.binarise()
+        with torch.cuda.stream(s2):
+            a.finish()                                               # the second half on another stream than the first
+        torch.cuda.synchronize(a_ctx.dev)
+        assert [a.tags(c) for c in range(80)] == want_a
+        assert [b.tags(c) for c in range(4)] == want_b
+
+
 def test_command_line_compress_and_restore(tmp_path):
     """`python -m losslessh264_amd in.264 out.pip out.yuv` writes the reference console application's files (names and bytes), the
     YUV dump has the SHA-1 of the reference's decoder test, and `... out.pip back.264` gives the input back"""

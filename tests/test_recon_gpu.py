@@ -152,6 +152,30 @@ def test_big_geometries_match_oracle():
                 assert np.array_equal(got[p], dst.padded_plane(p)), (name, i, p)
 
 
+@pytest.mark.parametrize("name", ["syn720p_allI_4slices_8f.264", "syn1080p_IP_8f.264", "tibby.264"])
+def test_bench_streams_match_oracle(name):
+    """the streams bench.py runs (--config 2 / 3: the 8-picture 720p and 1080p streams; BASELINE.json configs[0]: tibby.264), all
+    pictures: host front end -> HIP reconstruct, every padded plane of every picture against the oracle.  68 macroblock rows on 8
+    waves over eight 1080p pictures: the cross-picture wait_prefix path of recon_chain_kernel beyond the first two pictures."""
+    import os
+    import losslessh264_amd as lh
+    frames, err = lh.parse_stream(open(os.path.join(golden_io.GOLDEN_DIR, "streams", name), "rb").read())
+    assert err == "" and len(frames) >= 8
+    sess = lh.ReconSession([frames], replicate=2)
+    sess.run(); sess.synchronize()
+    pics = {}
+    for i, f in enumerate(frames):
+        dst = O.HostPic(f.mb_w, f.mb_h)
+        O.recon_frame(f.mbs, f.coeffs, f.slices, dst, [pics[r] for r in f.ref_ids], 0)
+        pics[f.id] = dst
+        for c in (0, 1):
+            got = sess.picture(c, i, padded=True)
+            for p in range(3):
+                assert np.array_equal(got[p], dst.padded_plane(p)), (name, c, i, p)
+        for old in [k for k in pics if k not in f.ref_ids and k != f.id and all(k not in g.ref_ids for g in frames[i + 1:])]:
+            del pics[old]
+
+
 def test_chain_with_resolution_change():
     """frames of different sizes in one chain (the row cursor of the pipelined wavefront crosses pictures of different
     heights; a new intra picture starts each segment, as after an SPS change)"""

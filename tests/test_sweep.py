@@ -24,8 +24,11 @@ MAIN_DIFFERS = {"test_scalinglist_jm.264"}
 # the tagged streams differ (or the stream is refused as a whole) for exactly these
 TAGS_DIFFER = {"test_scalinglist_jm.264", "Error_I_P.264", "BA_MW_D_IDR_LOST.264"}
 # restore (compress (stream)) is not the stream for exactly these (BA_MW_D_IDR_LOST and test_scalinglist_jm do come back: what the
-# front end cannot model stays in the default stream)
+# front end cannot model stays in the default stream).  Error_I_P has pictures with macroblocks no slice covers; the reference conceals
+# them, this code does not: the compress call must REFUSE the stream (an error, so that callers store it verbatim), not hand out a
+# representation that does not restore
 NO_RESTORE = {"Error_I_P.264"}
+REFUSED = {"Error_I_P.264"}
 # our one addition to the reference's file set: the samples of I_PCM macroblocks (include/lh264.h LH264_TAG_PCM), which the reference
 # does not store (its own restore aborts on such streams)
 TAG_PCM = 70
@@ -73,6 +76,7 @@ def test_compress_all_streams_on_the_gpu_and_restore():
     datas = [_data(n) for n in STREAMS]
     res = lh.compress_batch(datas, 16)
     tags_differ, no_restore, restored_ref_fails = set(), set(), set()
+    assert {name for name, r in zip(STREAMS, res) if r[2] is not None} == REFUSED
     for name, data, (main, tags, err) in zip(STREAMS, datas, res):
         ref = SWEEP[name]["files"]
         assert err is not None or (TAG_PCM in tags) == (name in HAVE_PCM), name
