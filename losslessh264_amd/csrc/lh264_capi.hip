@@ -54,6 +54,17 @@ void read_stamps (unsigned long long* out, bool reset);
 #endif
 }
 
+// the stream-per-workgroup form of the coder's first stages (lh264_coder_sw.hip)
+namespace lh264sw {
+__global__ void coder_jobs_kernel (const lh264_code_job_t* jobs, const int32_t* chain_first, int n_jobs, int n_chains, uint32_t* seg0, uint32_t* job_chain, uint32_t* chain_info);
+__global__ void coder_count_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, int n_jobs, uint32_t* seg_cnt);
+__global__ void coder_scan_kernel (const uint32_t* seg0, const int32_t* chain_first, const uint32_t* seg_cnt, uint32_t* seg_doff, uint32_t* chain_info, int n_chains);
+__global__ void coder_bases_kernel (uint32_t* chain_info, int n_chains, unsigned long long* totals);
+__global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* job_chain, int n_jobs,
+                                   const uint32_t* seg_doff, const uint32_t* chain_info, uint64_t* D);
+__global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint64_t* D, uint16_t* Q, int n_chains);
+}
+
 static thread_local std::string g_err;
 static int fail (int code, const char* what, hipError_t e = hipSuccess) {
   char buf[256];
@@ -226,7 +237,7 @@ struct CoderWs {
   uint32_t* pair_chunk0 = nullptr; uint32_t* pair_bits = nullptr; uint32_t* chunk_rec = nullptr; uint32_t* acc = nullptr;
   uint32_t* pair_coarse0 = nullptr; uint32_t* seed = nullptr; uint32_t* coarse_bits = nullptr; size_t coarse_bound = 0; int n_pairs_last = 0;
   uint32_t* cand = nullptr; uint8_t* cand_end = nullptr;
-  const uint32_t* seg0 = nullptr; const uint32_t* seg_doff = nullptr; const uint32_t* seg_part = nullptr; const int32_t* chain_first = nullptr; int log2p = 3;
+  const uint32_t* seg0 = nullptr; const uint32_t* seg_doff = nullptr; const uint32_t* seg_part = nullptr; const int32_t* chain_first = nullptr; int log2p = 3; bool sw = false;
 };
 CoderWs g_coder_ws[16];
 int grow (void** p, size_t* cap, size_t need) {
@@ -248,36 +259,58 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   W.ready_chains = -1;
   if (W.enter (st)) return fail (LH264_E_HIP, "hipStreamWaitEvent (coder work memory)");
   if (!W.totals_host) HIPCHK (hipHostMalloc ((void**)&W.totals_host, 2 * sizeof (unsigned long long), hipHostMallocDefault));
-  // the partitions of a stream's DynProbs (each resolved by a wave of its own): enough of them to fill the machine with waves
-  // (as few as fill the machine with waves: a partition's runs of decision words get shorter with their number, and a run costs its
-  // wave a look at the segment tables; LH264_CODER_LOG2P overrides, for experiments)
-  int log2p = 3;
-  while (log2p < LH264_CODER_MAX_LOG2P && ((long long)n_chains << log2p) < 8192) log2p++;
+  // Two forms of the first stages (binarisation, adaptive probabilities), chosen per call:
+  //   stream per workgroup (lh264_coder_sw.hip): a stream's decisions in coding order, one workgroup of 8 waves resolves them - the
+  //     faster form when the batch has hundreds of streams of moderate size (one LDS cache per stream, 512 decisions per step)
+  //   wave per (stream, partition) (lh264_coder.hip): scales inside a stream - few, large streams
+  // LH264_CODER_PATH=sw|wave overrides, for the tests (both forms must give the same bytes) and for experiments.
+  bool sw = n_chains >= 384 && total_mbs / n_chains <= 12288;
+  if (const char* e = getenv ("LH264_CODER_PATH")) { if (!strcmp (e, "sw")) sw = true; else if (!strcmp (e, "wave")) sw = false; }
+  W.sw = sw;
+  // the partitions of a stream's DynProbs (each resolved by a wave of its own): as few as fill the machine with waves - a partition's
+  // runs of decision words get shorter with their number, and a run costs its wave a look at the segment tables
+  // (LH264_CODER_LOG2P overrides, for experiments)
+  int log2p = n_chains > 512 ? 3 : 4;       // (measured: 512 x 16 and 256 x 16 beat 512 x 8 and 256 x 32, 1024 x 8 is enough waves)
+  while (log2p < LH264_CODER_MAX_LOG2P && ((long long)n_chains << log2p) < 2048) log2p++;
   if (const char* e = getenv ("LH264_CODER_LOG2P")) { const int v = atoi (e); if (v >= 0 && v <= LH264_CODER_MAX_LOG2P) log2p = v; }
   W.log2p = log2p;
   const size_t pstride = ((size_t)1 << log2p) + 1;
-  // small tables.  A picture of n macroblocks is cut into ceil (n / LH264_CODER_SEG_MBS) segments
-  const size_t seg_bound = (size_t)total_mbs / LH264_CODER_SEG_MBS + (size_t)n_jobs + 1;
+  // small tables.  A picture of n macroblocks is cut into ceil (n / segment size) segments
+  const size_t seg_mbs = sw ? LH264_CODER_SW_SEG_MBS : LH264_CODER_SEG_MBS;
+  const size_t seg_bound = (size_t)total_mbs / seg_mbs + (size_t)n_jobs + 1;
   const size_t o_seg0 = 0, o_jobchain = up256 ((size_t) (n_jobs + 1) * 4), o_info = o_jobchain + up256 ((size_t) (n_jobs + 1) * 4),
                o_totals = o_info + up256 ((size_t)n_chains * LH264_CODER_INFO_WORDS * 4), o_doff = o_totals + 256,
                o_sjob = o_doff + up256 (seg_bound * 4 + 4), o_cnt = o_sjob + up256 (seg_bound * 4 + 4), o_part = o_cnt + up256 (seg_bound * LH264_CODER_CNT_STRIDE * 4 + 4),
-               small_need = o_part + up256 (seg_bound * pstride * 4 + 4);
+               small_need = o_part + up256 (sw ? 4 : seg_bound * pstride * 4 + 4);
   if (int rc = grow (&W.small, &W.small_cap, small_need)) return rc;
   uint8_t* sm = (uint8_t*)W.small;
   uint32_t* seg0 = (uint32_t*) (sm + o_seg0); uint32_t* job_chain = (uint32_t*) (sm + o_jobchain); uint32_t* info = (uint32_t*) (sm + o_info);
   unsigned long long* totals = (unsigned long long*) (sm + o_totals); uint32_t* seg_doff = (uint32_t*) (sm + o_doff); uint32_t* seg_cnt = (uint32_t*) (sm + o_cnt);
   uint32_t* seg_part = (uint32_t*) (sm + o_part); uint32_t* seg_job = (uint32_t*) (sm + o_sjob);
-  hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, (unsigned)seg_bound, seg0, seg_job, job_chain, info);
-  HIPCHK (hipGetLastError());
   const unsigned seg_blocks = (unsigned) ((seg_bound + 3) / 4);
-  if (n_jobs > 0 && total_mbs > 0) {
-    hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, n_jobs, log2p, seg_cnt, seg_part);
+  if (sw) {
+    hipLaunchKernelGGL (lh264sw::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, seg0, job_chain, info);
+    HIPCHK (hipGetLastError());
+    if (n_jobs > 0 && total_mbs > 0) {
+      hipLaunchKernelGGL (lh264sw::coder_count_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, n_jobs, seg_cnt);
+      HIPCHK (hipGetLastError());
+    }
+    hipLaunchKernelGGL (lh264sw::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_cnt, seg_doff, info, n_chains);
+    HIPCHK (hipGetLastError());
+    hipLaunchKernelGGL (lh264sw::coder_bases_kernel, dim3 (1), dim3 (1024), 0, st, info, n_chains, totals);
+    HIPCHK (hipGetLastError());
+  } else {
+    hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, (unsigned)seg_bound, seg0, seg_job, job_chain, info);
+    HIPCHK (hipGetLastError());
+    if (n_jobs > 0 && total_mbs > 0) {
+      hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, n_jobs, log2p, seg_cnt, seg_part);
+      HIPCHK (hipGetLastError());
+    }
+    hipLaunchKernelGGL (lh264::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_cnt, seg_doff, info, n_chains);
+    HIPCHK (hipGetLastError());
+    hipLaunchKernelGGL (lh264::coder_bases_kernel, dim3 (1), dim3 (1024), 0, st, info, n_chains, totals);
     HIPCHK (hipGetLastError());
   }
-  hipLaunchKernelGGL (lh264::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_cnt, seg_doff, info, n_chains);
-  HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_bases_kernel, dim3 (1), dim3 (1024), 0, st, info, n_chains, totals);
-  HIPCHK (hipGetLastError());
   // the sizes of the decision words and of the tag lists are only known now
   HIPCHK (hipMemcpyAsync (W.totals_host, totals, 2 * sizeof (unsigned long long), hipMemcpyDeviceToHost, st));
   HIPCHK (hipStreamSynchronize (st));
@@ -305,7 +338,8 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   W.seg0 = seg0; W.seg_doff = seg_doff; W.seg_part = seg_part; W.chain_first = chain_first_dev;
   HIPCHK (hipMemsetAsync (acc, 0, n_acc * 4, st));
   if (n_jobs > 0 && total_mbs > 0) {
-    hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, job_chain, n_jobs, log2p, seg_doff, seg_cnt, seg_part, info, D);
+    if (sw) hipLaunchKernelGGL (lh264sw::coder_emit_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, job_chain, n_jobs, seg_doff, info, D);
+    else hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, job_chain, n_jobs, log2p, seg_doff, seg_cnt, seg_part, info, D);
     HIPCHK (hipGetLastError());
   }
   W.info = info; W.D = D; W.Q = Q; W.pair_chunk0 = pair_chunk0; W.pair_bits = pair_bits; W.chunk_rec = chunk_rec; W.acc = acc;
@@ -322,8 +356,9 @@ static int code_finish (CoderWs& W, const lh264_code_stream_t* streams_dev, int 
   const size_t chunk_bound = W.chunk_bound; const int n_pairs = W.n_pairs;
   W.ready_chains = -1;
   if (W.enter (st)) return fail (LH264_E_HIP, "hipStreamWaitEvent (coder work memory)");
-  hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 ((unsigned) ((((size_t)n_chains << W.log2p) + 3) / 4)), dim3 (256), 0, st, streams_dev, info, W.seg0, W.chain_first,
-                      W.seg_doff, W.seg_part, D, Q, n_chains, W.log2p);
+  if (W.sw) hipLaunchKernelGGL (lh264sw::coder_resolve_kernel, dim3 (n_chains), dim3 (LH264_CODER_RESOLVE_THREADS), 0, st, streams_dev, info, D, Q, n_chains);
+  else hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 ((unsigned) ((((size_t)n_chains << W.log2p) + 3) / 4)), dim3 (256), 0, st, streams_dev, info, W.seg0, W.chain_first,
+                           W.seg_doff, W.seg_part, D, Q, n_chains, W.log2p);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_status_kernel, dim3 ((n_chains + 255) / 256), dim3 (256), 0, st, streams_dev, info, n_chains);
   HIPCHK (hipGetLastError());
@@ -347,7 +382,7 @@ static int code_finish (CoderWs& W, const lh264_code_stream_t* streams_dev, int 
   hipLaunchKernelGGL (lh264::coder_accum_kernel, dim3 ((unsigned) ((chunk_bound + 255) / 256)), dim3 (256), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs,
                       chunk_rec, W.coarse_bits, pair_bits, acc);
   HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_bytes_kernel, dim3 ((unsigned) ((n_pairs + 63) / 64)), dim3 (64), 0, st, streams_dev, info, Q, pair_bits, acc, n_pairs);
+  hipLaunchKernelGGL (lh264::coder_bytes_kernel, dim3 ((unsigned) ((n_pairs + 3) / 4)), dim3 (256), 0, st, streams_dev, info, Q, pair_bits, acc, n_pairs);
   HIPCHK (hipGetLastError());
   // tag slots 35 .. LH264_N_TAG_SLOTS-1 do not exist: their lengths read 0
   if (W.leave (st)) return fail (LH264_E_HIP, "hipEventRecord (coder work memory)");

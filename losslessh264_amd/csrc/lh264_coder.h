@@ -3,9 +3,11 @@
 #define LH264_CODER_INTERNAL_H_
 #include "../../include/lh264.h"
 
-// the parallel binarisation works on segments of at most this many consecutive macroblocks of a picture, one wave each (<= 32: the wave
+// the parallel binarisation works on segments of at most this many consecutive macroblocks of a picture, one wave each (<= 64: the wave
 // lays a segment out with a lane per macroblock and 16-bit counters per lane)
-#define LH264_CODER_SEG_MBS 32
+#define LH264_CODER_SEG_MBS 64
+// (the stream-per-workgroup form, lh264_coder_sw.hip: a workgroup of 256 threads per segment, a thread per macroblock)
+#define LH264_CODER_SW_SEG_MBS 128
 // per-segment decision counts (32-bit): [0 .. LH264_N_TAG_SLOTS-1] per tag slot (bit 31: the segment brings the tag's stream into
 // existence), [LH264_N_TAG_SLOTS] all decisions of the segment
 #define LH264_CODER_CNT_STRIDE (LH264_N_TAG_SLOTS + 1)
@@ -39,7 +41,7 @@
 // the range recurrence of a tag's list is walked in coarse chunks of this many decisions (a multiple of LH264_CODER_CODE_CHUNK), each
 // from a start state found by looking back over the decisions in front of it (coder_range_seed_kernel)
 #ifndef LH264_CODER_CODE_COARSE
-#define LH264_CODER_CODE_COARSE 16384
+#define LH264_CODER_CODE_COARSE 65536
 #endif
 
 // status bits reported in out_len_dev[LH264_N_TAG_SLOTS]

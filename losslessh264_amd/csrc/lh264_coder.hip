@@ -166,69 +166,64 @@ template <class S> __device__ __forceinline__ void binarize (S& s, uint32_t prio
   }
 }
 
+#define CODER_RAW_KEY 0xf8000000u
 // ---- how many decisions a symbol becomes, per tag, without walking its binarisation (same cases as binarize above) -------------
-struct SymCount { int n, s0, s1, s2, s3, n0, n1, n2, n3, tch; };      // at most four tags (slots; -1: unused), tch: tag brought into existence
-// the tail of emitInt behind its zero flag / sign: exponent (unary) and mantissa decisions of data >= 1 (after the sign)
-__device__ __forceinline__ void cnt_int_tail (int data, int order, int& ne, int& nm) {
-  data--;
-  const int l2 = 31 - __clz (1 + (data >> order));
-  ne += l2 + 1; nm += l2 + order;
-}
+// n: all decisions; up to four (tag slot, count) pairs (-1: unused); tch: tag brought into existence; raws: how many of the decisions are
+// raw bits (the shared TEST_PROB); key: the cell the others use (trees over several cells: the first one).
+// The lanes of a wave hold symbols of all kinds: the integer-like ones (DC, nonzero count, coefficient, motion vector difference -
+// emitInt / emitUEGkInt with different constants) go through ONE instruction stream with the constants in registers, not through a
+// branch per kind (round-3 counters: 19 of 64 lanes were active on average in the per-kind version).
+struct SymCount { int n, s0, s1, s2, s3, n0, n1, n2, n3, tch, raws; uint32_t key; };
 __device__ __forceinline__ SymCount sym_count (uint32_t prior, int value, int kind, int pad) {
   enum { T_LDC = 17, T_CRDC = 18, T_LAC_0_EOB = 19, T_LAC_N_EOB = 24, T_CRAC_EOB = 29 };
-  SymCount c; c.n = 0; c.s0 = c.s1 = c.s2 = c.s3 = -1; c.n0 = c.n1 = c.n2 = c.n3 = 0; c.tch = -1;
+  SymCount c; c.n = 0; c.s0 = c.s1 = c.s2 = c.s3 = -1; c.n0 = c.n1 = c.n2 = c.n3 = 0; c.tch = -1; c.raws = 0; c.key = prior;
   const int table = (int) (prior >> 27);
-  switch (kind) {
-  case LH264_SYM_LUMA_DC: case LH264_SYM_CHROMA_DC: case LH264_SYM_NZ4: case LH264_SYM_NZ8: {
-    const bool dc = kind == LH264_SYM_LUMA_DC || kind == LH264_SYM_CHROMA_DC;
-    const int t = kind == LH264_SYM_LUMA_DC ? T_LDC : kind == LH264_SYM_CHROMA_DC ? T_CRDC : (((prior / 27u) % 3u) ? T_CRAC_EOB : T_LAC_0_EOB);
-    int n = 1, ne = 0, nm = 0;                                   // the zero flag
-    if (value != 0) { if (dc) n++; cnt_int_tail (value < 0 ? -value : value, 0, ne, nm); }      // sign (DC only), exponent, mantissa
-    c.n = n + ne + nm; c.s0 = t; c.n0 = c.n;
-    break; }
-  case LH264_SYM_AC4: case LH264_SYM_AC8: {
-    const uint32_t nco = kind == LH264_SYM_AC4 ? 16u : 64u;
-    const uint32_t outer = prior / 3125u;
-    const int emitted = (int) (outer % nco), color = (int) ((outer / nco) % 3u), code = (int) ((outer / nco / 3u) % 16u);
-    const int first = color == 0 && emitted == 0 && code != 1;
-    const int base = color ? T_CRAC_EOB : (first ? T_LAC_0_EOB : T_LAC_N_EOB);
-    c.tch = base + 2;
-    int nz = 1, ns = 0, ne = 0, nm = 0;
+  const bool ac = kind == LH264_SYM_AC4 || kind == LH264_SYM_AC8, mvd = kind == LH264_SYM_MVD;
+  const bool dc = kind == LH264_SYM_LUMA_DC || kind == LH264_SYM_CHROMA_DC, nzk = kind == LH264_SYM_NZ4 || kind == LH264_SYM_NZ8;
+  if (ac || mvd || dc || nzk) {
+    // [zero flag] [sign] [unary up to N ones; beyond it: zero flag of the escape] [emitInt tail: l2 + 1 exponent, l2 + order mantissa decisions]
+    const int N = ac ? 14 : mvd ? 9 : 0, order = mvd ? 3 : 0;
+    const int av = value < 0 ? -value : value;
+    int nz = 1, ns = 0, ne = 0, nm = 0, data = 0;
     if (value != 0) {
-      ns = 1;
-      const int u = (value < 0 ? -value : value) - 1;
-      nm = u >= 14 ? 14 : u + 1;
-      if (u >= 14) { nz++; if (u - 14 != 0) cnt_int_tail (u - 14, 0, ne, nm); }
+      ns = nzk ? 0 : 1;
+      if (N) { const int u = av - 1; nm = u >= N ? N : u + 1; if (u >= N) { nz++; data = u - N; } }
+      else data = av;
+    }
+    if (data > 0) {
+      const int a = data - 1, high = 1 + (a >> order), l2 = 31 - __clz (high), nb = l2 + order;
+      ne = l2 + 1; nm += nb;
+      // raw bits: the mantissa decisions beyond the binary search over its four priors (man_place < 0)
+      const int b0 = 0 < l2 ? (high >> (l2 - 1)) & 1 : (a >> ((order - 1) & 31)) & 1, b1 = 1 < l2 ? (high >> ((l2 - 2) & 31)) & 1 : (a >> ((order - 2 + l2) & 31)) & 1;
+      c.raws = nb <= 2 ? 0 : nb - 2 - ((!b0 && !b1) ? 1 : 0);
     }
     c.n = nz + ns + ne + nm;
-    c.s0 = base + 1; c.n0 = nz;
-    if (ns) { c.s1 = base + 4; c.n1 = ns; }
-    if (nm) { c.s2 = base + 3; c.n2 = nm; }
-    if (ne) { c.s3 = base + 2; c.n3 = ne; }
-    break; }
-  case LH264_SYM_BIT: c.n = 1; break;
-  case LH264_SYM_RAW: c.n = (int)prior > 0 ? (int)prior : 0; break;
-  case LH264_SYM_MVD: {                                         // UEGk<9,4,3,4,3>
-    int n = 1, ne = 0, nm = 0;
-    if (value != 0) {
-      n++;
-      const int u = (value < 0 ? -value : value) - 1;
-      nm = u >= 9 ? 9 : u + 1;
-      if (u >= 9) { n++; if (u - 9 != 0) cnt_int_tail (u - 9, 3, ne, nm); }
+    c.key = mvd ? prior : LH264_PRIOR (kind == LH264_SYM_LUMA_DC ? LH264_TB_LDC : kind == LH264_SYM_CHROMA_DC ? LH264_TB_CDC : kind == LH264_SYM_NZ4 ? LH264_TB_NZ4 :
+                                       kind == LH264_SYM_NZ8 ? LH264_TB_NZ8 : kind == LH264_SYM_AC4 ? LH264_TB_AC4 : LH264_TB_AC8, prior);
+    if (ac) {                                                   // tags by colour / first scan position (encode4x4)
+      const uint32_t nco = kind == LH264_SYM_AC4 ? 16u : 64u;
+      const uint32_t outer = prior / 3125u;
+      const int emitted = (int) (outer % nco), color = (int) ((outer / nco) % 3u), code = (int) ((outer / nco / 3u) % 16u);
+      const int first = color == 0 && emitted == 0 && code != 1;
+      const int base = color ? T_CRAC_EOB : (first ? T_LAC_0_EOB : T_LAC_N_EOB);
+      c.tch = tag_slot (base + 2);
+      c.s0 = tag_slot (base + 1); c.n0 = nz;
+      if (ns) { c.s1 = tag_slot (base + 4); c.n1 = ns; }
+      if (nm) { c.s2 = tag_slot (base + 3); c.n2 = nm; }
+      if (ne) { c.s3 = tag_slot (base + 2); c.n3 = ne; }
+    } else {
+      c.s0 = tag_slot (mvd ? pad : kind == LH264_SYM_LUMA_DC ? T_LDC : kind == LH264_SYM_CHROMA_DC ? T_CRDC : (((prior / 27u) % 3u) ? T_CRAC_EOB : T_LAC_0_EOB));
+      c.n0 = c.n;
     }
-    c.n = n + ne + nm;
-    break; }
-  case LH264_SYM_TREE: c.n = table == LH264_TB_SKIPRUN ? 9 : table == LH264_TB_SUBMB ? 8 : table == LH264_TB_CBPC ? 2 : 4; break;
-  case LH264_SYM_POW2: {
-    const bool qpl = table == LH264_TB_QPL;
-    const unsigned preferred = qpl ? 0u : (prior & 0x7ffffffu), data = (unsigned) (uint16_t)value;
-    c.n = 1 + (data != preferred ? (qpl ? 7 : 3) : 0);
-    break; }
-  default: break;
+    return c;
   }
-  if (kind >= LH264_SYM_TREE && c.n > 0) { c.s0 = tag_slot (pad); c.n0 = c.n; }      // the host's symbols name their tag
-  else { if (c.s0 >= 0) c.s0 = tag_slot (c.s0); if (c.s1 >= 0) c.s1 = tag_slot (c.s1); if (c.s2 >= 0) c.s2 = tag_slot (c.s2); if (c.s3 >= 0) c.s3 = tag_slot (c.s3); }
-  if (c.tch >= 0) c.tch = tag_slot (c.tch);
+  const bool qpl = table == LH264_TB_QPL;
+  const unsigned preferred = qpl ? 0u : (prior & 0x7ffffffu);
+  c.n = kind == LH264_SYM_BIT ? 1 : kind == LH264_SYM_RAW ? ((int)prior > 0 ? (int)prior : 0) :
+        kind == LH264_SYM_TREE ? (table == LH264_TB_SKIPRUN ? 9 : table == LH264_TB_SUBMB ? 8 : table == LH264_TB_CBPC ? 2 : 4) :
+        kind == LH264_SYM_POW2 ? 1 + ((unsigned) (uint16_t)value != preferred ? (qpl ? 7 : 3) : 0) : 0;
+  if (kind == LH264_SYM_RAW) { c.raws = c.n; c.key = CODER_RAW_KEY; }
+  if (c.n > 0) { c.s0 = tag_slot (pad); c.n0 = c.n; }          // the host's symbols name their tag
   return c;
 }
 
@@ -236,7 +231,6 @@ __device__ __forceinline__ SymCount sym_count (uint32_t prior, int value, int ki
 // The parallel binarisation works a lane per DECISION: the j-th decision of a symbol follows from kind, value and j alone.
 // key: the cell of the DynProb (LH264_PRIOR form), place: its place in the cell; raw bits (coded with the shared TEST_PROB,
 // compression_stream.h:363,441-448) carry CODER_RAW_KEY, place 0.
-#define CODER_RAW_KEY 0xf8000000u
 struct Decision { uint32_t key; int place, bit, tag; };
 // place of mantissa decision i in emitInt's binary search over 4 mantissa priors (:559-571), given the two bits before it; -1: raw
 __device__ __forceinline__ int man_place (int i, int b0, int b1) { return i == 0 ? 2 : i == 1 ? (b0 ? 3 : 1) : (i == 2 && !b0 && !b1) ? 0 : -1; }
@@ -350,8 +344,8 @@ __device__ __forceinline__ bool seg_locate (const lh264_code_job_t* jobs, const 
 __device__ __forceinline__ void seg_layout (LDS SegLds& L, Seg& S, int lane) {
   const GLB uint32_t* off = glb<const uint32_t> (S.J->syn_off_dev) + S.k0;
   const GLB uint16_t* cn = glb<const uint16_t> (S.J->ctx_n_syms_dev) + S.k0;
-  if (lane <= S.n) L.hoff[lane] = off[lane];
-  if (lane < S.n) { L.mc[lane] = cn[lane]; L.p[lane] = 0xffffu; }
+  if (lane < S.n) { L.hoff[lane] = off[lane]; L.mc[lane] = cn[lane]; L.p[lane] = 0xffffu; }
+  if (lane == 0) L.hoff[S.n] = off[S.n];
   wsync();
   // the markers: every host symbol of the segment is looked at once
   const GLB uint64_t* hs = glb<const uint64_t> (S.J->syn_syms_dev);
@@ -364,7 +358,7 @@ __device__ __forceinline__ void seg_layout (LDS SegLds& L, Seg& S, int lane) {
     }
   }
   wsync();
-  // symbols per macroblock, running sum (at most 32 macroblocks: one per lane)
+  // symbols per macroblock, running sum (at most 64 macroblocks: one per lane)
   uint32_t v = 0;
   if (lane < S.n) { const uint32_t nh = L.hoff[lane + 1] - L.hoff[lane]; v = L.p[lane] != 0xffffu ? nh - 1u + L.mc[lane] : nh; }
   const uint32_t incl = (uint32_t)wave_scan_add ((int)v);
@@ -382,6 +376,29 @@ __device__ __forceinline__ uint64_t seg_symbol (const LDS SegLds& L, const Seg& 
   if (i < p || p == 0xffffu) return hs[i];
   if (i < p + mc) return glb<const uint64_t> (S.J->ctx_syms_dev)[(size_t) (S.k0 + (int)lo) * LH264_CTX_MAX_SYMS + (i - p)];
   return hs[i - mc + 1u];
+}
+// symbols s0 + 64 q + lane, q = 0 .. 3, of the segment (0 beyond its end): the four searches advance together, so that a step waits for
+// LDS once, not four times, and the four loads are under way together
+__device__ __forceinline__ void seg_symbol4 (const LDS SegLds& L, const Seg& S, uint32_t s0, int lane, uint64_t out[4]) {
+  uint32_t s[4], lo[4], hi[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { s[q] = s0 + 64u * (uint32_t)q + (uint32_t)lane; lo[q] = 0; hi[q] = (uint32_t)S.n; }
+  for (int it = 0; it < 7; it++) {                        // S.n <= 64: six halvings (a seventh step changes nothing)
+    uint32_t v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = L.sbase[(lo[q] + hi[q]) >> 1];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint32_t mid = (lo[q] + hi[q]) >> 1; if (hi[q] - lo[q] > 1u) { if (v[q] <= s[q]) lo[q] = mid; else hi[q] = mid; } }
+  }
+  const GLB uint64_t* hsb = glb<const uint64_t> (S.J->syn_syms_dev);
+  const GLB uint64_t* cs = glb<const uint64_t> (S.J->ctx_syms_dev);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint32_t i = s[q] - L.sbase[lo[q]], p = L.p[lo[q]], mc = p != 0xffffu ? L.mc[lo[q]] : 0u;
+    const GLB uint64_t* hs = hsb + L.hoff[lo[q]];
+    const GLB uint64_t* src = (i < p || p == 0xffffu) ? hs + i : i < p + mc ? cs + (size_t) (S.k0 + (int)lo[q]) * LH264_CTX_MAX_SYMS + (i - p) : hs + (i - mc + 1u);
+    out[q] = s[q] < S.total ? *src : 0ull;
+  }
 }
 
 // ---- kernel 0: segments before each picture; which stream a picture belongs to ----------------------------------------------------
@@ -425,7 +442,7 @@ coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __r
 // p's run starts inside the segment's decision words.
 // Counters: one 16-bit column per lane in LDS ([slot][lane], two lanes to a dword) - the symbols of a step mostly count towards the
 // same few tags, and 64 lanes adding to one LDS word take 64 turns (that was the round-2 kernel's whole time); a lane's column is
-// its own bank.  A lane sees at most 16.9 K / 64 symbols of at most 46 decisions: the columns cannot overflow.
+// its own bank.  A lane sees at most 64 x 528 / 64 symbols of at most 46 decisions: the 16-bit columns cannot overflow.
 // raw decisions behind emitInt's zero flag and sign (the mantissa bits beyond its four priors, man_place < 0)
 __device__ __forceinline__ int int_tail_raws (int data, int order) {
   const int a = data - 1, high = 1 + (a >> order), l2 = 31 - __clz (high), nb = l2 + order;
@@ -471,8 +488,7 @@ coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* _
   for (uint32_t s0 = 0; s0 < S.total; s0 += 256u) {
     // four symbols per lane and step: their loads are under way together
     uint64_t sy[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) { const uint32_t s = s0 + 64u * (uint32_t)q + (uint32_t)lane; sy[q] = s < S.total ? seg_symbol (L.seg, S, s) : 0ull; }
+    seg_symbol4 (L.seg, S, s0, lane, sy);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const uint64_t sym = sy[q];
@@ -492,14 +508,8 @@ coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* _
       if (multi) {
         for (int j = 0; j < c.n; j++) padd (cell_part (decision_at (prior, value, kind, pad, j).key, log2p), 1u);
       } else if (c.n > 0) {
-        int raws = 0;
-        const int av = value < 0 ? -value : value;
-        if (kind == LH264_SYM_RAW) raws = c.n;
-        else if (kind == LH264_SYM_LUMA_DC || kind == LH264_SYM_CHROMA_DC || kind == LH264_SYM_NZ4 || kind == LH264_SYM_NZ8) { if (value != 0) raws = int_tail_raws (av, 0); }
-        else if (kind == LH264_SYM_AC4 || kind == LH264_SYM_AC8) { if (av - 1 > 14) raws = int_tail_raws (av - 1 - 14, 0); }
-        else if (kind == LH264_SYM_MVD) { if (av - 1 > 9) raws = int_tail_raws (av - 1 - 9, 3); }
-        if (raws) padd (praw, (uint32_t)raws);
-        if (c.n > raws) padd (cell_part (sym_key (prior, kind), log2p), (uint32_t) (c.n - raws));
+        if (c.raws) padd (praw, (uint32_t)c.raws);
+        if (c.n > c.raws) padd (cell_part (c.key, log2p), (uint32_t) (c.n - c.raws));
       }
     }
   }
@@ -647,8 +657,8 @@ coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __
     // order, with the number of the batch's decisions in front of each, and a bit is set where each one's decisions start
     for (int i = lane; i < EMIT_BATCH * 46 / 32 + 2; i += 64) L.starts[i] = 0;
     uint64_t sy[EMIT_BATCH / 64];
-#pragma unroll
-    for (int q = 0; q < EMIT_BATCH / 64; q++) { const uint32_t s = b0 + 64u * (uint32_t)q + (uint32_t)lane; sy[q] = s < S.total ? seg_symbol (L.seg, S, s) : 0ull; }
+    static_assert (EMIT_BATCH == 256, "seg_symbol4");
+    seg_symbol4 (L.seg, S, b0, lane, sy);
     wsync();
     uint32_t run = 0, kept = 0;
 #pragma unroll
@@ -1188,6 +1198,7 @@ __device__ __forceinline__ uint32_t coarse_pair (const uint32_t* __restrict__ pa
 }
 
 #define CODE_LOOKBACK 1024u
+#define CODE_LONG_LIST 262144u
 #define CODE_CANDS 8
 __global__ void __launch_bounds__ (256)
 coder_range_seed_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_coarse0, int n_pairs,
@@ -1198,6 +1209,9 @@ coder_range_seed_kernel (const uint32_t* __restrict__ chain_info, const uint16_t
   const uint32_t c = G - pair_coarse0[pair];
   if (c == 0u) { if (lane < 2u) cand[2 * (size_t)G + lane] = lane == 0u ? 255u : 0u; return; }
   const PairInfo P = pair_info (chain_info, Q, pair);
+  // a list of moderate length is walked whole by the lane of its first chunk (10 ns a decision: 2.6 ms at most) - candidates cost
+  // several walks per chunk, which only pays where one lane would take longer than the rest of the coder
+  if (P.total <= CODE_LONG_LIST) { if (lane < 2u) cand[2 * (size_t)G + lane] = 0u; return; }
   const uint32_t b = c * CODE_COARSE;
   uint32_t r0 = 128u + lane, r1 = 192u + lane;
   for (uint32_t i0 = b - CODE_LOOKBACK; i0 < b; i0 += 64u) {
@@ -1430,61 +1444,65 @@ coder_accum_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __r
 
 // kernel 9: carries, bytes, lengths.  vpx_write puts a byte out whenever 8 more bits have been shifted out beyond the first 24:
 // bytes = (bits - 24) / 8 + 1; byte k is byte position k of the sum.  vpx_stop_encode appends a zero byte behind a last byte 110xxxxx.
-__global__ void __launch_bounds__ (64)
+// One WAVE per pair, 64 positions per step from the last to the first (round 2: one lane per pair, a position at a time - 30 ms for the
+// 1080p batch's megabyte tags).  A position's sum holds up to 32 bits, i.e. it reaches three positions up; two local steps bring
+// every position down to a digit of at most 258 - B[k] = the bytes of A[k .. k+3] that fall on k (< 1024), C[k] = B[k] mod 256 + B[k+1]
+// div 256 - and from there on a carry is one bit: a position generates one (C >= 256), passes one on (C == 255) or ends it.  The
+// carries into the 64 positions of a step are then ONE 64-bit addition of the two lane masks (the adder's own carry chain does the
+// work: carries = ((G | P) + G + carry_in) ^ P), and the carry out of the step goes into the next.
+__global__ void __launch_bounds__ (256)
 coder_bytes_kernel (const lh264_code_stream_t* __restrict__ streams, const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q,
                     const uint32_t* __restrict__ pair_bits, const uint32_t* __restrict__ acc, int n_pairs) {
-  const uint32_t pair = blockIdx.x * 64u + threadIdx.x;
+  const uint32_t pair = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (pair >= (uint32_t)n_pairs) return;
   const uint32_t chain = pair / LH264_N_TAG_SLOTS, slot = pair % LH264_N_TAG_SLOTS;
   if (slot >= 35u) return;                             // tag slots that do not exist (their lengths are cleared by the status kernel)
   const lh264_code_stream_t* S = streams + chain;
   GLB uint32_t* lens = glb<uint32_t> (S->out_len_dev);
   const PairInfo P = pair_info (chain_info, Q, pair);
-  if (!P.used) { lens[slot] = 0; return; }
+  if (!P.used) { if (lane == 0u) lens[slot] = 0; return; }
   const uint32_t bits = pair_bits[pair], cap = S->out_cap;
   uint32_t nbytes = bits >= 24u ? ((bits - 24u) >> 3) + 1u : 0u;
   const GLB uint32_t* A = glb<const uint32_t> (acc) + P.acc0;
   GLB uint8_t* o = glb<uint8_t> (S->out_dev) + (size_t)slot * cap;
-  // sums behind the last byte that is put out carry into it as well
-  uint32_t carry = 0;
-  const uint32_t last = (bits >> 3) + 2u;                      // no addend lies behind this position
-  for (uint32_t k = last; k + 1u > nbytes; k--) carry = (A[k] + carry) >> 8;           // positions last .. nbytes
-  uint32_t final_byte = 0;
-  uint32_t k = nbytes;
-  for (; (k & 3u) != 0u; ) {                          // down to a multiple of four positions, then four sums (and four bytes) at a time
-    k--;
-    const uint32_t v = A[k] + carry;
-    carry = v >> 8;
-    if (k < cap) o[k] = (uint8_t)v;
-    if (k == nbytes - 1u) final_byte = v & 0xffu;
-  }
   const bool wide = (((uintptr_t)o) & 3u) == 0u;
-  // four positions (and four bytes) per step; the sums are read four steps ahead of the carry chain (code_ld16 / code_wait: the loop
-  // would otherwise wait for every load it has just issued)
-  auto four = [&] (const u32x4 q) {
-    k -= 4u;
-    const uint32_t v3 = q.w + carry, v2 = q.z + (v3 >> 8), v1 = q.y + (v2 >> 8), v0 = q.x + (v1 >> 8);
-    carry = v0 >> 8;
-    if (k + 3u == nbytes - 1u) final_byte = v3 & 0xffu;
-    const uint32_t word = (v0 & 0xffu) | (v1 & 0xffu) << 8 | (v2 & 0xffu) << 16 | (v3 & 0xffu) << 24;
-    if (wide && k + 3u < cap) * (GLB uint32_t*) (o + k) = word;
-    else { if (k < cap) o[k] = (uint8_t)v0; if (k + 1u < cap) o[k + 1] = (uint8_t)v1; if (k + 2u < cap) o[k + 2] = (uint8_t)v2; if (k + 3u < cap) o[k + 3] = (uint8_t)v3; }
-  };
-  u32x4 f0 = {0u, 0u, 0u, 0u}, f1 = f0, f2 = f0, f3 = f0;
-  code_ld16 (f0, (const GLB u32x4*) (A + (k >= 4u ? k - 4u : 0u)));
-  code_ld16 (f1, (const GLB u32x4*) (A + (k >= 8u ? k - 8u : 0u)));
-  code_ld16 (f2, (const GLB u32x4*) (A + (k >= 12u ? k - 12u : 0u)));
-  code_ld16 (f3, (const GLB u32x4*) (A + (k >= 16u ? k - 16u : 0u)));
-#define CODE_TURN(F) code_wait<3> (F); four (F); code_ld16 (F, (const GLB u32x4*) (A + (k >= 16u ? k - 16u : 0u)));
-  while (k >= 16u) { CODE_TURN (f0) CODE_TURN (f1) CODE_TURN (f2) CODE_TURN (f3) }
-#undef CODE_TURN
-  code_wait<0> (f0); code_wait<0> (f1); code_wait<0> (f2); code_wait<0> (f3);
-  if (k >= 4u) four (f0);
-  if (k >= 4u) four (f1);
-  if (k >= 4u) four (f2);
-  if (nbytes > 0u && (final_byte & 0xe0u) == 0xc0u) { if (nbytes < cap) o[nbytes] = 0; nbytes++; }
-  lens[slot] = nbytes;
-  if (nbytes > cap) atomicOr ((uint32_t*) (uintptr_t) (lens + LH264_N_TAG_SLOTS), (uint32_t)LH264_CODER_ST_OUT_FULL);
+  const uint32_t last = (bits >> 3) + 2u;                      // no addend lies behind this position (the sums behind it read zero)
+  uint32_t cin = 0, final_byte = 0;
+  // lane i of a step holds position k0 + 63 - i: bit i of a lane mask is then the bit a carry moves UP from towards bit i + 1
+  for (uint32_t k0 = last & ~63u; ; k0 -= 64u) {
+    const uint32_t k = k0 + 63u - lane;
+    // (behind `last` the next pair's sums begin: read as zero)
+    const uint32_t a0 = k <= last ? A[k] : 0u, a1 = k + 1u <= last ? A[k + 1u] : 0u, a2 = k + 2u <= last ? A[k + 2u] : 0u,
+                   a3 = k + 3u <= last ? A[k + 3u] : 0u, a4 = k + 4u <= last ? A[k + 4u] : 0u;
+    const uint32_t B0 = (a0 & 255u) + ((a1 >> 8) & 255u) + ((a2 >> 16) & 255u) + (a3 >> 24);
+    const uint32_t B1 = (a1 & 255u) + ((a2 >> 8) & 255u) + ((a3 >> 16) & 255u) + (a4 >> 24);
+    const uint32_t C = (B0 & 255u) + (B1 >> 8);
+    const unsigned long long G = __ballot (C >= 256u), Pm = __ballot (C == 255u);
+    const unsigned long long X = G | Pm, s1 = X + G, s2 = s1 + cin;
+    const uint32_t cout = (s1 < X || s2 < s1) ? 1u : 0u;
+    const unsigned long long carries = s2 ^ Pm;                // bit i: the carry INTO position k0 + 63 - i
+    const uint32_t byte = (C + (uint32_t) ((carries >> lane) & 1ull)) & 255u;
+    cin = cout;
+    if (nbytes > 0u && k == nbytes - 1u) final_byte = byte;
+    // four positions to a dword: lane i (i % 4 == 0) holds position k, lanes i + 1 .. i + 3 positions k - 1 .. k - 3
+    const uint32_t b1 = (uint32_t)__shfl_down ((int)byte, 1), b2 = (uint32_t)__shfl_down ((int)byte, 2), b3 = (uint32_t)__shfl_down ((int)byte, 3);
+    if ((lane & 3u) == 0u && k - 3u < nbytes) {
+      if (wide && k < nbytes && k < cap) * (GLB uint32_t*) (o + (k - 3u)) = b3 | b2 << 8 | b1 << 16 | byte << 24;
+      else {
+        if (k - 3u < nbytes && k - 3u < cap) o[k - 3u] = (uint8_t)b3;
+        if (k - 2u < nbytes && k - 2u < cap) o[k - 2u] = (uint8_t)b2;
+        if (k - 1u < nbytes && k - 1u < cap) o[k - 1u] = (uint8_t)b1;
+        if (k < nbytes && k < cap) o[k] = (uint8_t)byte;
+      }
+    }
+    if (k0 == 0u) break;
+  }
+  final_byte = (uint32_t)__builtin_amdgcn_readlane (wave_scan_add ((int)final_byte), 63);      // (one lane held it)
+  if (lane == 0u) {
+    if (nbytes > 0u && (final_byte & 0xe0u) == 0xc0u) { if (nbytes < cap) o[nbytes] = 0; nbytes++; }
+    lens[slot] = nbytes;
+    if (nbytes > cap) atomicOr ((uint32_t*) (uintptr_t) (lens + LH264_N_TAG_SLOTS), (uint32_t)LH264_CODER_ST_OUT_FULL);
+  }
 }
 
 // the status word of every stream, before the coding kernel adds its own bit

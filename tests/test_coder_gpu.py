@@ -20,8 +20,11 @@ def _frames(name, z):
     return frames[:len(z["hdr"])]
 
 
-def test_device_coder_equals_reference_bytes():
+@pytest.mark.parametrize("path", ["sw", "wave"])
+def test_device_coder_equals_reference_bytes(path, monkeypatch):
+    """both forms of the coder's first stages (stream per workgroup / wave per (stream, partition), csrc/lh264_capi.hip code_binarise)"""
     import losslessh264_amd as lh
+    monkeypatch.setenv("LH264_CODER_PATH", path)
     streams, refs = [], []
     for name in FIXTURES:
         z = np.load(os.path.join(golden_io.GOLDEN_DIR, "pip_" + name + ".npz"))
@@ -87,10 +90,12 @@ CLI = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(golden_io
 CLI_CAVLC = [n for n in CLI if "cabac" not in n.lower()]
 
 
-def test_whole_stream_compress_equals_reference_cli_and_round_trips():
+@pytest.mark.parametrize("path", ["sw", "wave"])
+def test_whole_stream_compress_equals_reference_cli_and_round_trips(path, monkeypatch):
     """.264 -> (default stream from the host front end, tagged streams from the HIP coder) == the files the reference's console
-    application writes; and those restore (csrc/host/pip_restore.cpp) to the input, bit for bit"""
+    application writes; and those restore (csrc/host/pip_restore.cpp) to the input, bit for bit.  Both forms of the coder's first stages."""
     import losslessh264_amd as lh
+    monkeypatch.setenv("LH264_CODER_PATH", path)
     datas, streams, mains, pcms = [], [], [], []
     for name in CLI:
         data = open(os.path.join(golden_io.GOLDEN_DIR, "streams", name), "rb").read()

@@ -67,12 +67,14 @@ def test_default_stream_equals_reference_on_all_but_the_named_streams():
 
 
 @pytest.mark.gpu
-def test_compress_all_streams_on_the_gpu_and_restore():
+@pytest.mark.parametrize("path", ["sw", "wave"])
+def test_compress_all_streams_on_the_gpu_and_restore(path, monkeypatch):
     """the whole compress direction (front end -> HIP context-index + coder kernels) over all 44 streams in one batch: every file
     equals the reference's (SHA-1) except for the named streams; what equals the reference's files restores to the input (so the
     reference's own files do), including 9 streams the reference itself aborts on (two of them with I_PCM macroblocks, whose
     samples travel in our additional stream LH264_TAG_PCM)"""
     import losslessh264_amd as lh
+    monkeypatch.setenv("LH264_CODER_PATH", path)                 # both forms of the coder's first stages (csrc/lh264_capi.hip code_binarise)
     datas = [_data(n) for n in STREAMS]
     res = lh.compress_batch(datas, 16)
     tags_differ, no_restore, restored_ref_fails = set(), set(), set()
