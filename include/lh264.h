@@ -265,7 +265,14 @@ typedef struct lh264_code_stream {
  * chain_first_dev: n_chains + 1 entries (stream c codes jobs_dev[chain_first[c] .. chain_first[c+1]-1] in order); n_jobs = all
  * pictures, total_mbs = the sum of their n_mbs, max_mbs_per_frame = the largest n_mbs.  The call sizes its work memory (kept
  * between calls, per device) from a count pass, so it synchronises hip_stream once in the middle; the tagged streams are complete
- * when hip_stream has drained.  out_len_dev[LH264_N_TAG_SLOTS] != 0 reports 1: prior table full, 4: output overflow, 8: counter overflow. */
+ * when hip_stream has drained.  out_len_dev[LH264_N_TAG_SLOTS] != 0 reports (bits): 1 prior table full or hash_cap invalid (not a power of
+ * two, zero, above 1 << 20, or - with the per-partition tables of large streams - below 8 entries x the partition count), 4 output
+ * overflow (the lengths then say how much room is needed), 8 counter overflow (2^32 decisions or 2^27 list entries in one stream, or
+ * total_mbs smaller than the pictures' macroblock counts), 16 internal (a hand-off between the waves of a stream timed out / the range
+ * walk lost its state: the result is wrong; never seen outside broken development builds).  Any non-zero status: the stream's tagged
+ * bytes must not be used.
+ * Coder calls share one set of work memory per device: calls on different HIP streams are ordered on the device by an event (a later call
+ * waits for the earlier one's kernels), calls on one stream by the stream. */
 int lh264_code_chains (const lh264_code_job_t* jobs_dev, const int32_t* chain_first_dev, const lh264_code_stream_t* streams_dev,
                        int n_chains, int n_jobs, long long total_mbs, int max_mbs_per_frame, void* hip_stream);
 /* The same in two calls, for a caller that wants to put other work between the halves (the second half - the adaptive probabilities

@@ -90,7 +90,7 @@ class CoderSession:
         n = L.N_TAG_SLOTS
         lens = self.d_len[chain * (n + 1):(chain + 1) * (n + 1)].cpu().numpy()
         if lens[n] != 0:
-            raise RuntimeError("device coder status %d (1: prior table full, 4: output overflow)" % lens[n])
+            raise RuntimeError("device coder status %d (bits - 1: prior table full or invalid, 4: output overflow, 8: counter overflow, 16: internal)" % lens[n])
         base = chain * n * self.out_cap
         out = {}
         for slot in range(len(TAG_OF_SLOT)):

@@ -723,10 +723,14 @@ coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __
 // and the halving is done by the next reader.  An entry of the wave's LDS cache (and of the spill table in HBM) is 64 bits: counters in
 // bits 0..19, the DynProb's key (cell key << 4 | place, 36 bits) in bits 20..55, bit 63 set.  All zero = free.
 #define R2_WAVES 4
+#ifndef R2_LOG2_BUCKETS
 #define R2_LOG2_BUCKETS 8
+#endif
 #define R2_SLOTS (4 << R2_LOG2_BUCKETS)        // DynProbs in a wave's LDS cache: 1024
-// Decision words are requested R2_DEPTH + 3 rounds before they are resolved (a round takes about 0.5 us, a word under load 2 .. 3 us to arrive)
-#define R2_DEPTH 6
+// Decision words are requested R2_DEPTH + 3 rounds before they are resolved
+#ifndef R2_DEPTH
+#define R2_DEPTH 3      // (measured: 6 slots cost a workgroup's worth of LDS per CU and bought nothing - 36 vs 29 ms on 512 x 4 720p pictures)
+#endif
 #define R2_CHECK 4               // the fill of the cache is looked at every R2_CHECK rounds (that many rounds insert <= 256)
 #ifndef R2_FLUSH
 #define R2_FLUSH 600             // everything goes to the spill table and the cache starts over above this many

@@ -202,7 +202,7 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   for (int c = 0; c < n_chains; c++) {
     lh264_compressed_t& r = *out[idx[c]];
     const uint32_t* L = &lens[(size_t)c * (LH264_N_TAG_SLOTS + 1)];
-    if (L[LH264_N_TAG_SLOTS] != 0) { r.status = LH264_E_HIP; r.error = "device coder status " + std::to_string (L[LH264_N_TAG_SLOTS]) + " (1: prior table full, 4: output overflow, 8: counter overflow)"; continue; }
+    if (L[LH264_N_TAG_SLOTS] != 0) { r.status = LH264_E_HIP; r.error = "device coder status " + std::to_string (L[LH264_N_TAG_SLOTS]) + " (bits - 1: prior table full or invalid, 4: output overflow, 8: counter overflow, 16: internal hand-off; include/lh264.h)"; continue; }
     for (int slot = 0; slot < 35; slot++) if (L[slot]) {
         PackItem it; it.src = out0[c] + (size_t)slot * out_cap[c]; it.dst = packed_bytes; it.len = L[slot]; it.pad = (uint32_t)c << 8 | (uint32_t)slot;
         items.push_back (it);

@@ -20,7 +20,13 @@ def run(name, frames, streams):
     print("== %s streams=%d  cycles/MB(sum over phases)=%.0f" % (name, streams, tot / s.n_mbs_total))
     for i in range(11):
         print("   %-24s %6.1f%%  %8.0f cyc/MB" % (names[i], 100.0 * buf[i] / tot, buf[i] / s.n_mbs_total))
-ba = golden_io.load("bench_BA_MW_D.264")[:20]
-run("BA_MW_D", ba, 1)
-run("BA_MW_D", ba, 512)
-run("intra", synth.make_stream(1, 11, 9, 4, p_frames=False), 512)
+if len(sys.argv) > 1:            # tools/stamp_probe.py STREAM N [FRAMES]
+    fr, err = lh.parse_stream(open(os.path.join(ROOT, "tests", "golden", "streams", sys.argv[1]), "rb").read())
+    if len(sys.argv) > 3:
+        fr = fr[:int(sys.argv[3])]
+    run(sys.argv[1], fr, int(sys.argv[2]))
+else:
+    ba = golden_io.load("bench_BA_MW_D.264")[:20]
+    run("BA_MW_D", ba, 1)
+    run("BA_MW_D", ba, 512)
+    run("intra", synth.make_stream(1, 11, 9, 4, p_frames=False), 512)
