@@ -31,7 +31,7 @@ __global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32
                                       const uint32_t* seg_doff, const uint32_t* seg_part, const uint64_t* D, uint16_t* Q, int n_chains, int log2p);
 __global__ void coder_chunkmap_kernel (const uint32_t* chain_info, int n_pairs, uint32_t* pair_chunk0, uint32_t* pair_coarse0);
 __global__ void coder_range_seed_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_coarse0, int n_pairs, uint32_t* cand);
-__global__ void coder_range_walk1_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs,
+__global__ void coder_range_walk1_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs, int groups,
                                           const uint32_t* cand, uint8_t* cand_end, uint32_t* chunk_rec, uint32_t* coarse_bits);
 __global__ void coder_range_cand_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs,
                                          const uint32_t* cand, uint8_t* cand_end);
@@ -367,7 +367,11 @@ static int code_finish (CoderWs& W, const lh264_code_stream_t* streams_dev, int 
   // the bool coders' range recurrence in coarse chunks: start states by lookback, the walk, the running sum of the bits
   hipLaunchKernelGGL (lh264::coder_range_seed_kernel, dim3 ((unsigned) ((W.coarse_bound + 3) / 4)), dim3 (256), 0, st, info, Q, W.pair_coarse0, n_pairs, W.cand);
   HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_range_walk1_kernel, dim3 ((unsigned) ((W.coarse_bound + 63) / 64)), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs,
+  const int groups = (n_chains + 63) / 64;
+  hipLaunchKernelGGL (lh264::coder_range_walk1_kernel, dim3 ((unsigned)groups * 35), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs, groups,
+                      W.cand, W.cand_end, chunk_rec, W.coarse_bits);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::coder_range_walk1_kernel, dim3 ((unsigned) ((W.coarse_bound + 63) / 64)), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs, 0,
                       W.cand, W.cand_end, chunk_rec, W.coarse_bits);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_range_cand_kernel, dim3 ((unsigned) ((W.coarse_bound + 7) / 8)), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs, W.cand, W.cand_end);

@@ -1311,13 +1311,25 @@ __device__ __forceinline__ uint32_t range_walk (const uint32_t* __restrict__ cha
   }
   return A.range;
 }
-// one lane per coarse chunk with ONE candidate (every list's first chunk is one): that is its start state - the final walk at once
+// one lane per coarse chunk with ONE candidate (every list's first chunk is one): that is its start state - the final walk at once.
+// Two launches: `groups` > 0 - the first chunks of all lists, a wave = one tag slot of 64 consecutive streams (lists of about the same
+// length in its lanes: a wave is as slow as its longest list); `groups` == 0 - the later chunks with one candidate, a lane per chunk.
 __global__ void __launch_bounds__ (64)
 coder_range_walk1_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0,
-                          const uint32_t* __restrict__ pair_coarse0, int n_pairs, const uint32_t* __restrict__ cand, uint8_t* __restrict__ cand_end,
+                          const uint32_t* __restrict__ pair_coarse0, int n_pairs, int groups, const uint32_t* __restrict__ cand, uint8_t* __restrict__ cand_end,
                           uint32_t* __restrict__ chunk_rec, uint32_t* __restrict__ coarse_bits) {
-  const uint32_t G = blockIdx.x * 64u + threadIdx.x;
-  if (G >= pair_coarse0[n_pairs]) return;
+  uint32_t G;
+  if (groups > 0) {
+    const uint32_t slot = blockIdx.x / (uint32_t)groups, chain = (blockIdx.x % (uint32_t)groups) * 64u + threadIdx.x;
+    const uint32_t pair = chain * LH264_N_TAG_SLOTS + slot;
+    if (pair >= (uint32_t)n_pairs) return;
+    G = pair_coarse0[pair];
+    if (pair_coarse0[pair + 1] == G) return;             // the tag has no list
+  } else {
+    G = blockIdx.x * 64u + threadIdx.x;
+    if (G >= pair_coarse0[n_pairs]) return;
+    if (G == pair_coarse0[coarse_pair (pair_coarse0, (uint32_t)n_pairs, G)]) return;      // a first chunk: the other launch's
+  }
   const uint32_t c0 = cand[2 * (size_t)G], c1 = cand[2 * (size_t)G + 1];
   if (c0 == 0u || (c0 >> 8) != 0u || c1 != 0u) return;
   cand_end[(size_t)G * CODE_CANDS] = (uint8_t)range_walk<true> (chain_info, Q, pair_chunk0, pair_coarse0, n_pairs, cand, G, c0, chunk_rec, coarse_bits);
