@@ -282,7 +282,7 @@ def main():
     # reconstructed and coded, the context indices of batch j are computed on a third stream, behind the binarisation of i - beside the
     # resolve kernel and the bool coder's kernels, whose waves mostly wait.  Every step still launches every kernel of rows a1-a10 once;
     # the second batch is a second set of device buffers with the same streams (synthetic input).  Only where that second set fits easily.
-    pipeline = not args.no_pipeline and ctx.n_mbs_total * 4400 < 40e9
+    pipeline = not args.no_pipeline and ctx.n_mbs_total * 930 + ctx.n_syms_total * 8 < 40e9      # (records, levels, images + the symbol pool)
     ctxs, coders = [ctx], [coder]
     if pipeline:
         ctxs.append(lh.CtxSession(order, device=local_rank, replicate=rep))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LH264_ABI_VERSION 2
+#define LH264_ABI_VERSION 3
 
 /* ---- macroblock types: the reference's own flag values (codec/common/inc/wels_common_defs.h:264-281) */
 #define LH264_MB_I4x4      0x0001
@@ -225,15 +225,29 @@ typedef struct lh264_ctx_job {
   const lh264_slice_t* slices_dev;
   const uint8_t*       nnz_past_dev;  /* mb_w*mb_h*24 or NULL (no PAST)                          */
   uint8_t*             nnz_cur_dev;   /* mb_w*mb_h*24, written by pass 1, read by pass 2 and later frames */
-  lh264_ctx_sym_t*     syms_dev;      /* mb_w*mb_h*LH264_CTX_MAX_SYMS, first n_syms[mb] valid, emission order */
+  lh264_ctx_sym_t*     syms_dev;      /* the symbols, emission order.  FIXED layout (sym_off_dev == NULL): mb_w*mb_h*LH264_CTX_MAX_SYMS slots,
+                                         macroblock k at k*LH264_CTX_MAX_SYMS, first n_syms[k] valid.  COMPACT layout: see below       */
   uint16_t*            n_syms_dev;    /* mb_w*mb_h                                               */
   int32_t  mb_w, mb_h;
+  /* COMPACT layout (ABI 3; sym_off_dev != NULL): the jobs of a call share ONE pool of symbols - syms_dev is the pool's first symbol in
+   * every job, syms_cap its size in symbols -, macroblock k of this picture lies at syms_dev[*sym_base_dev + sym_off_dev[k]].  Both
+   * are WRITTEN by the call (a count pass over the levels: 8 bytes per coded symbol, a macroblock's run padded to a multiple of 8
+   * symbols = a 64-byte line, instead of 3,456 bytes per macroblock).  The pool is
+   * sized from lh264_ctx_count_chains; a pool that is too small is not written to (every n_syms reads 0, *total_dev tells the need). */
+  uint32_t*            sym_off_dev;   /* mb_w*mb_h offsets (symbols) behind the picture's first symbol              */
+  uint64_t*            sym_base_dev;  /* this picture's first symbol in the pool (one word per job)                 */
+  uint64_t             syms_cap;      /* symbols there is room for at syms_dev                                      */
 } lh264_ctx_job_t;
 
 /* chains as in lh264_recon_chains (frames of one stream in order: the nnz image of a frame may be the PAST of a
  * later one).  Pass 1 (nnz images) runs one workgroup per chain, pass 2 (symbols) one wave per macroblock. */
 int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
                             int n_jobs, int max_mbs_per_frame, void* hip_stream);
+/* COMPACT layout, first half: pass 1 and the count alone - fills n_syms_dev, sym_off_dev and *sym_base_dev of every job and
+ * *total_dev = the symbols of all jobs (what the pool must hold).  lh264_ctx_index_chains repeats this on its own: the call exists so
+ * that the caller can size the pool. */
+int lh264_ctx_count_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
+                            int n_jobs, int max_mbs_per_frame, unsigned long long* total_dev, void* hip_stream);
 
 /* ---- rows a9 + a10 + f4: the adaptive binary arithmetic coder, on the device -----------------------------------
  * Consumes, per macroblock in coding order, the host list of syntax symbols (with the SPLICE marker where the
@@ -249,9 +263,11 @@ int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chai
 typedef struct lh264_code_job {
   const lh264_ctx_sym_t* syn_syms_dev;   /* host symbols of the picture, macroblock after macroblock        */
   const uint32_t*        syn_off_dev;    /* n_mbs + 1 offsets into syn_syms_dev                             */
-  const lh264_ctx_sym_t* ctx_syms_dev;   /* n_mbs * LH264_CTX_MAX_SYMS (lh264_ctx_job_t.syms_dev)           */
+  const lh264_ctx_sym_t* ctx_syms_dev;   /* lh264_ctx_job_t.syms_dev: n_mbs * LH264_CTX_MAX_SYMS, or the pool    */
   const uint16_t*        ctx_n_syms_dev; /* n_mbs                                                           */
   int32_t n_mbs, reserved;
+  const uint32_t*        ctx_sym_off_dev;  /* lh264_ctx_job_t.sym_off_dev (NULL: the fixed layout)          */
+  const uint64_t*        ctx_sym_base_dev; /* lh264_ctx_job_t.sym_base_dev                                  */
 } lh264_code_job_t;
 typedef struct lh264_code_stream {
   uint32_t* hash_keys_dev;     /* not used (ABI 1 kept the keys of the table here)                          */

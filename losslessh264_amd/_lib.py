@@ -97,10 +97,11 @@ _SIGS.update({
     "lh264_parser_frame_syn_offsets": (C.c_void_p, [C.c_void_p, C.c_int]),
     "lh264_parser_error": (C.c_char_p, [C.c_void_p]),
 })
-CODE_JOB_DTYPE = np.dtype([("syn_syms", "<u8"), ("syn_off", "<u8"), ("ctx_syms", "<u8"), ("ctx_n_syms", "<u8"), ("n_mbs", "<i4"), ("reserved", "<i4")])
+CODE_JOB_DTYPE = np.dtype([("syn_syms", "<u8"), ("syn_off", "<u8"), ("ctx_syms", "<u8"), ("ctx_n_syms", "<u8"), ("n_mbs", "<i4"), ("reserved", "<i4"),
+                           ("ctx_sym_off", "<u8"), ("ctx_sym_base", "<u8")])
 CODE_STREAM_DTYPE = np.dtype([("hash_keys", "<u8"), ("hash_cells", "<u8"), ("out", "<u8"), ("out_len", "<u8"), ("hash_cap", "<u4"), ("out_cap", "<u4")])
 N_TAG_SLOTS = 40
-assert CODE_JOB_DTYPE.itemsize == 40 and CODE_STREAM_DTYPE.itemsize == 40
+assert CODE_JOB_DTYPE.itemsize == 56 and CODE_STREAM_DTYPE.itemsize == 40
 _SIGS["lh264_code_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_void_p])
 _SIGS["lh264_code_binarise_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_void_p])
 _SIGS["lh264_code_finish_chains"] = (C.c_int, [C.c_void_p, C.c_int, C.c_void_p])
@@ -148,13 +149,16 @@ MBSYN_DTYPE = np.dtype([
 assert MBSYN_DTYPE.itemsize == 116
 CTX_SYM_DTYPE = np.dtype([("prior", "<u4"), ("value", "<i2"), ("kind", "u1"), ("pad", "u1")])
 CTX_JOB_DTYPE = np.dtype([("mbs", "<u8"), ("levels", "<u8"), ("slices", "<u8"), ("nnz_past", "<u8"), ("nnz_cur", "<u8"),
-                          ("syms", "<u8"), ("n_syms", "<u8"), ("mb_w", "<i4"), ("mb_h", "<i4")])
+                          ("syms", "<u8"), ("n_syms", "<u8"), ("mb_w", "<i4"), ("mb_h", "<i4"),
+                          ("sym_off", "<u8"), ("sym_base", "<u8"), ("syms_cap", "<u8")])
 CTX_MAX_SYMS = 432
-assert CTX_SYM_DTYPE.itemsize == 8 and CTX_JOB_DTYPE.itemsize == 64
+assert CTX_SYM_DTYPE.itemsize == 8 and CTX_JOB_DTYPE.itemsize == 88
 _SIGS["lh264_ctx_index_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p])
-CODE_JOB_DTYPE = np.dtype([("syn_syms", "<u8"), ("syn_off", "<u8"), ("ctx_syms", "<u8"), ("ctx_n_syms", "<u8"), ("n_mbs", "<i4"), ("reserved", "<i4")])
+_SIGS["lh264_ctx_count_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+CODE_JOB_DTYPE = np.dtype([("syn_syms", "<u8"), ("syn_off", "<u8"), ("ctx_syms", "<u8"), ("ctx_n_syms", "<u8"), ("n_mbs", "<i4"), ("reserved", "<i4"),
+                           ("ctx_sym_off", "<u8"), ("ctx_sym_base", "<u8")])
 CODE_STREAM_DTYPE = np.dtype([("hash_keys", "<u8"), ("hash_cells", "<u8"), ("out", "<u8"), ("out_len", "<u8"), ("hash_cap", "<u4"), ("out_cap", "<u4")])
 N_TAG_SLOTS = 40
-assert CODE_JOB_DTYPE.itemsize == 40 and CODE_STREAM_DTYPE.itemsize == 40
+assert CODE_JOB_DTYPE.itemsize == 56 and CODE_STREAM_DTYPE.itemsize == 40
 _SIGS["lh264_code_chains"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_void_p])
 EXPORTS = sorted(_SIGS)

@@ -45,6 +45,7 @@ class CoderSession:
         jobs = np.zeros(ctx.n_jobs, dtype=L.CODE_JOB_DTYPE)
         bs, bo = self.d_syn.data_ptr(), self.d_off.data_ptr()
         by, bc = ctx.d_syms.data_ptr(), ctx.d_nsyms.data_ptr()
+        b_symoff, b_symbase = ctx.d_symoff.data_ptr(), ctx.d_symbase.data_ptr()
         j = 0
         for c in range(n_chains):
             ii = info[c % len(streams)]
@@ -52,7 +53,8 @@ class CoderSession:
                 g = ctx.job_mb_off[j]
                 jb = jobs[j]
                 jb["syn_syms"], jb["syn_off"] = bs + s0 * 8, bo + o0 * 4
-                jb["ctx_syms"], jb["ctx_n_syms"] = by + g * L.CTX_MAX_SYMS * 8, bc + g * 2
+                jb["ctx_syms"], jb["ctx_n_syms"] = by, bc + g * 2               # (the compact layout: one pool for all pictures)
+                jb["ctx_sym_off"], jb["ctx_sym_base"] = b_symoff + g * 4, b_symbase + j * 8
                 jb["n_mbs"] = n
                 j += 1
         st = np.zeros(n_chains, dtype=L.CODE_STREAM_DTYPE)

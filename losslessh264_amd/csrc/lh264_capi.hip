@@ -21,6 +21,9 @@ __global__ void recon_chain_kernel (const lh264_frame_job_t* jobs, const int32_t
 __global__ void ctx_nnz_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
 __global__ void ctx_inherit_chain_kernel (const lh264_ctx_job_t* jobs, const int32_t* chain_first, int n_chains);
 __global__ void ctx_symbols_kernel (const lh264_ctx_job_t* jobs, int n_jobs, int blocks_per_job);
+__global__ void ctx_offsets_kernel (const lh264_ctx_job_t* jobs, int n_jobs, unsigned long long* job_total);
+__global__ void ctx_bases_kernel (int n_jobs, unsigned long long* job_total, unsigned long long* total);
+__global__ void ctx_scatter_kernel (const lh264_ctx_job_t* jobs, int n_jobs, const unsigned long long* job_total);
 __global__ void coder_jobs_kernel (const lh264_code_job_t* jobs, const int32_t* chain_first, int n_jobs, int n_chains, unsigned seg_bound, uint32_t* seg0, uint32_t* seg_job, uint32_t* job_chain, uint32_t* chain_info);
 __global__ void coder_count_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* seg_job, int n_jobs, int log2p, uint32_t* seg_cnt, uint32_t* seg_part);
 __global__ void coder_scan_kernel (const uint32_t* seg0, const int32_t* chain_first, uint32_t* seg_cnt, uint32_t* seg_doff, uint32_t* chain_info, int n_chains);
@@ -190,20 +193,54 @@ int lh264_recon_frames (const lh264_frame_job_t* jobs_dev, int n_jobs, int max_m
   return launch_chains (jobs_dev, idx_dev, n_jobs, max_mb_w, max_mb_h, st);
 }
 
-int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
-                            int n_jobs, int max_mbs_per_frame, void* stream) {
+// per device: the pictures' symbol totals of the compact layout (n_jobs + 1 words), kept between calls
+namespace {
+struct CtxWs { std::mutex mu; void* totals = nullptr; size_t cap = 0; };
+CtxWs g_ctx_ws[16];
+}
+static int ctx_passes (const lh264_ctx_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains, int n_jobs, int max_mbs_per_frame,
+                       unsigned long long* total_dev, bool symbols, hipStream_t st) {
   if (lh264_device_count() <= 0) return fail (LH264_E_NODEVICE, "no HIP device visible");
   if (!jobs_dev || !chain_first_dev || n_chains < 0 || n_jobs < 0 || max_mbs_per_frame <= 0) return fail (LH264_E_ARG, "bad argument");
-  if (n_chains == 0 || n_jobs == 0) return LH264_OK;
-  hipStream_t st = (hipStream_t)stream;
+  if (n_chains == 0 || n_jobs == 0) { if (total_dev) HIPCHK (hipMemsetAsync (total_dev, 0, 8, st)); return LH264_OK; }
+  int dev = 0;
+  HIPCHK (hipGetDevice (&dev));
+  if (dev < 0 || dev >= 16) return fail (LH264_E_ARG, "device index out of range");
+  CtxWs& W = g_ctx_ws[dev];
+  std::lock_guard<std::mutex> lock (W.mu);
+  const size_t need = ((size_t)n_jobs + 2) * 8;
+  if (need > W.cap) {
+    if (W.totals) (void)hipFree (W.totals);            // (synchronises the device: nobody reads the old one any more)
+    W.totals = nullptr; W.cap = 0;
+    HIPCHK (hipMalloc (&W.totals, need + 4096));
+    W.cap = need + 4096;
+  }
   const int bpj = (max_mbs_per_frame + 3) / 4;
   hipLaunchKernelGGL (lh264::ctx_nnz_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, n_jobs, bpj);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::ctx_inherit_chain_kernel, dim3 (n_chains), dim3 (256), 0, st, jobs_dev, chain_first_dev, n_chains);
   HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::ctx_symbols_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, n_jobs, bpj);
+  // the compact layout: where every macroblock's symbols go (pictures in the fixed layout count as empty)
+  hipLaunchKernelGGL (lh264::ctx_offsets_kernel, dim3 (n_jobs), dim3 (256), 0, st, jobs_dev, n_jobs, (unsigned long long*)W.totals);
   HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::ctx_bases_kernel, dim3 (1), dim3 (1024), 0, st, n_jobs, (unsigned long long*)W.totals, total_dev);
+  HIPCHK (hipGetLastError());
+  hipLaunchKernelGGL (lh264::ctx_scatter_kernel, dim3 ((unsigned) ((n_jobs + 255) / 256)), dim3 (256), 0, st, jobs_dev, n_jobs, (const unsigned long long*)W.totals);
+  HIPCHK (hipGetLastError());
+  if (symbols) {
+    hipLaunchKernelGGL (lh264::ctx_symbols_kernel, dim3 ((unsigned)n_jobs * bpj), dim3 (256), 0, st, jobs_dev, n_jobs, bpj);
+    HIPCHK (hipGetLastError());
+  }
   return LH264_OK;
+}
+int lh264_ctx_index_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
+                            int n_jobs, int max_mbs_per_frame, void* stream) {
+  return ctx_passes (jobs_dev, chain_first_dev, n_chains, n_jobs, max_mbs_per_frame, nullptr, true, (hipStream_t)stream);
+}
+int lh264_ctx_count_chains (const lh264_ctx_job_t* jobs_dev, const int32_t* chain_first_dev, int n_chains,
+                            int n_jobs, int max_mbs_per_frame, unsigned long long* total_dev, void* stream) {
+  if (!total_dev) return fail (LH264_E_ARG, "bad argument");
+  return ctx_passes (jobs_dev, chain_first_dev, n_chains, n_jobs, max_mbs_per_frame, total_dev, false, (hipStream_t)stream);
 }
 
 // Work memory of the coder stages, kept between calls and grown on demand: one set per device.  The lock only serialises the host

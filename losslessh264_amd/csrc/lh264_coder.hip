@@ -367,6 +367,11 @@ __device__ __forceinline__ void seg_layout (LDS SegLds& L, Seg& S, int lane) {
   wsync();
   S.total = L.sbase[S.n];
 }
+// where the coefficient symbols of macroblock k of a picture start (in symbols behind ctx_syms_dev): its fixed slot, or - compact
+// layout - the picture's first symbol in the pool + the macroblock's offset
+__device__ __forceinline__ size_t ctx_sym_at (const lh264_code_job_t* J, int k) {
+  return J->ctx_sym_off_dev ? (size_t)*glb<const unsigned long long> (J->ctx_sym_base_dev) + glb<const uint32_t> (J->ctx_sym_off_dev)[k] : (size_t)k * LH264_CTX_MAX_SYMS;
+}
 // symbol s of the segment (coding order)
 __device__ __forceinline__ uint64_t seg_symbol (const LDS SegLds& L, const Seg& S, uint32_t s) {
   uint32_t lo = 0, hi = (uint32_t)S.n;                   // the macroblock that holds symbol s
@@ -374,7 +379,7 @@ __device__ __forceinline__ uint64_t seg_symbol (const LDS SegLds& L, const Seg& 
   const uint32_t i = s - L.sbase[lo], p = L.p[lo], mc = p != 0xffffu ? L.mc[lo] : 0u;
   const GLB uint64_t* hs = glb<const uint64_t> (S.J->syn_syms_dev) + L.hoff[lo];
   if (i < p || p == 0xffffu) return hs[i];
-  if (i < p + mc) return glb<const uint64_t> (S.J->ctx_syms_dev)[(size_t) (S.k0 + (int)lo) * LH264_CTX_MAX_SYMS + (i - p)];
+  if (i < p + mc) return glb<const uint64_t> (S.J->ctx_syms_dev)[ctx_sym_at (S.J, S.k0 + (int)lo) + (i - p)];
   return hs[i - mc + 1u];
 }
 // symbols s0 + 64 q + lane, q = 0 .. 3, of the segment (0 beyond its end): the four searches advance together, so that a step waits for
@@ -396,7 +401,7 @@ __device__ __forceinline__ void seg_symbol4 (const LDS SegLds& L, const Seg& S, 
   for (int q = 0; q < 4; q++) {
     const uint32_t i = s[q] - L.sbase[lo[q]], p = L.p[lo[q]], mc = p != 0xffffu ? L.mc[lo[q]] : 0u;
     const GLB uint64_t* hs = hsb + L.hoff[lo[q]];
-    const GLB uint64_t* src = (i < p || p == 0xffffu) ? hs + i : i < p + mc ? cs + (size_t) (S.k0 + (int)lo[q]) * LH264_CTX_MAX_SYMS + (i - p) : hs + (i - mc + 1u);
+    const GLB uint64_t* src = (i < p || p == 0xffffu) ? hs + i : i < p + mc ? cs + ctx_sym_at (S.J, S.k0 + (int)lo[q]) + (i - p) : hs + (i - mc + 1u);
     out[q] = s[q] < S.total ? *src : 0ull;
   }
 }

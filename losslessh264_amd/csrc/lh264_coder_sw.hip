@@ -314,6 +314,11 @@ __device__ __forceinline__ void seg_layout (LDS SegLds& L, Seg& S, int tid) {
   __syncthreads();
   S.total = L.sbase[S.n];
 }
+// where the coefficient symbols of macroblock k of a picture start (in symbols behind ctx_syms_dev): its fixed slot, or - compact
+// layout - the picture's first symbol in the pool + the macroblock's offset
+__device__ __forceinline__ size_t ctx_sym_at (const lh264_code_job_t* J, int k) {
+  return J->ctx_sym_off_dev ? (size_t)*glb<const unsigned long long> (J->ctx_sym_base_dev) + glb<const uint32_t> (J->ctx_sym_off_dev)[k] : (size_t)k * LH264_CTX_MAX_SYMS;
+}
 // symbol s of the segment (coding order)
 __device__ __forceinline__ uint64_t seg_symbol (const LDS SegLds& L, const Seg& S, uint32_t s) {
   uint32_t lo = 0, hi = (uint32_t)S.n;                   // the macroblock that holds symbol s
@@ -321,7 +326,7 @@ __device__ __forceinline__ uint64_t seg_symbol (const LDS SegLds& L, const Seg& 
   const uint32_t i = s - L.sbase[lo], p = L.p[lo], mc = p != 0xffffu ? L.mc[lo] : 0u;
   const GLB uint64_t* hs = glb<const uint64_t> (S.J->syn_syms_dev) + L.hoff[lo];
   if (i < p || p == 0xffffu) return hs[i];
-  if (i < p + mc) return glb<const uint64_t> (S.J->ctx_syms_dev)[(size_t) (S.k0 + (int)lo) * LH264_CTX_MAX_SYMS + (i - p)];
+  if (i < p + mc) return glb<const uint64_t> (S.J->ctx_syms_dev)[ctx_sym_at (S.J, S.k0 + (int)lo) + (i - p)];
   return hs[i - mc + 1u];
 }
 

@@ -77,7 +77,7 @@ struct PinBuf {                       // page-locked staging memory (the upload 
   template <typename T> T* as() const { return (T*)p; }
 };
 struct Arena {
-  DevBuf d_mbs, d_lev, d_sl, d_nnz, d_syms, d_nsyms, d_cj, d_first, d_syn, d_off, d_kj, d_st, d_keys, d_cells, d_out, d_len, d_items, d_packed;
+  DevBuf d_mbs, d_lev, d_sl, d_nnz, d_syms, d_nsyms, d_symoff, d_symbase, d_cj, d_first, d_syn, d_off, d_kj, d_st, d_keys, d_cells, d_out, d_len, d_items, d_packed;
   PinBuf h_mbs, h_sparse, h_sl, h_syn, h_off, h_packed;
   DevBuf d_sparse;
 };
@@ -136,7 +136,7 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   const size_t keys_total = key0[n_chains], out_total = out0[n_chains];
   const double t_a = now_s();
   const bool ok = A.d_mbs.alloc (n_mbs * sizeof (lh264_mb_t), false) && A.d_lev.alloc (n_mbs * 768, true) && A.d_sparse.alloc (n_sparse * 8, false) && A.d_sl.alloc (n_slices * sizeof (lh264_slice_t), false) &&
-                  A.d_nnz.alloc (n_mbs * 24, true) && A.d_syms.alloc (n_mbs * LH264_CTX_MAX_SYMS * sizeof (lh264_ctx_sym_t), false) && A.d_nsyms.alloc (n_mbs * 2, true) &&
+                  A.d_nnz.alloc (n_mbs * 24, true) && A.d_nsyms.alloc (n_mbs * 2, true) && A.d_symoff.alloc (n_mbs * 4, false) && A.d_symbase.alloc ((n_jobs + 2) * 8, false) &&
                   A.d_cj.alloc (n_jobs * sizeof (lh264_ctx_job_t), false) && A.d_first.alloc ((n_chains + 1) * 4, false) && A.d_syn.alloc (n_syn * sizeof (lh264_ctx_sym_t), false) &&
                   A.d_off.alloc (n_off * 4, false) && A.d_kj.alloc (n_jobs * sizeof (lh264_code_job_t), false) && A.d_st.alloc (n_chains * sizeof (lh264_code_stream_t), false) &&
                   A.d_keys.alloc (256, false) && A.d_cells.alloc (keys_total * 64, true) && A.d_out.alloc (out_total, false) &&
@@ -168,11 +168,14 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
       cj.mbs_dev = A.d_mbs.as<lh264_mb_t>() + mo; cj.levels_dev = A.d_lev.as<int16_t>() + mo * 384; cj.slices_dev = A.d_sl.as<lh264_slice_t>() + so;
       cj.nnz_cur_dev = A.d_nnz.as<uint8_t>() + mo * 24;
       cj.nnz_past_dev = past[i] < 0 ? nullptr : A.d_nnz.as<uint8_t>() + mb_at[past[i]] * 24;
-      cj.syms_dev = A.d_syms.as<lh264_ctx_sym_t>() + mo * LH264_CTX_MAX_SYMS; cj.n_syms_dev = A.d_nsyms.as<uint16_t>() + mo;
+      // (the compact layout: the pool's address and size are set once the count pass has said how many symbols there are)
+      cj.syms_dev = nullptr; cj.syms_cap = 0; cj.n_syms_dev = A.d_nsyms.as<uint16_t>() + mo;
+      cj.sym_off_dev = A.d_symoff.as<uint32_t>() + mo; cj.sym_base_dev = A.d_symbase.as<uint64_t>() + j;
       cj.mb_w = f.mb_w; cj.mb_h = f.mb_h;
       lh264_code_job_t& kj = h_kj[j];
       kj.syn_syms_dev = A.d_syn.as<lh264_ctx_sym_t>() + yo; kj.syn_off_dev = A.d_off.as<uint32_t>() + oo;
-      kj.ctx_syms_dev = cj.syms_dev; kj.ctx_n_syms_dev = cj.n_syms_dev; kj.n_mbs = (int32_t)n; kj.reserved = 0;
+      kj.ctx_syms_dev = nullptr; kj.ctx_n_syms_dev = cj.n_syms_dev; kj.n_mbs = (int32_t)n; kj.reserved = 0;
+      kj.ctx_sym_off_dev = cj.sym_off_dev; kj.ctx_sym_base_dev = cj.sym_base_dev;
       mo += n; so += f.slices.size(); yo += f.syn_syms.size(); oo += n + 1; j++;
     }
     lh264_code_stream_t& st = h_st[c];
@@ -191,7 +194,18 @@ void compress_group (Arena& A, std::vector<std::unique_ptr<lh264host::Parser>>& 
   if (n_sparse) hipLaunchKernelGGL (expand_levels_kernel, dim3 ((unsigned) ((n_sparse + 255) / 256)), dim3 (256), 0, nullptr, A.d_sparse.as<uint64_t>(), n_sparse, A.d_lev.as<int16_t>());
   if (trace_on()) hipDeviceSynchronize();
   const double t_d = now_s();
-  int rc = lh264_ctx_index_chains (A.d_cj.as<lh264_ctx_job_t>(), A.d_first.as<int32_t>(), n_chains, (int)n_jobs, max_mbs, nullptr);
+  // the symbol pool: the count pass says how many symbols the group's pictures have (8 bytes each; the fixed layout took 3,456 bytes per
+  // macroblock), then the job tables get the pool's address
+  unsigned long long n_syms_total = 0;
+  int rc = lh264_ctx_count_chains (A.d_cj.as<lh264_ctx_job_t>(), A.d_first.as<int32_t>(), n_chains, (int)n_jobs, max_mbs, A.d_symbase.as<unsigned long long>() + n_jobs + 1, nullptr);
+  if (rc == LH264_OK && hipMemcpy (&n_syms_total, A.d_symbase.as<unsigned long long>() + n_jobs + 1, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = LH264_E_HIP;
+  if (rc == LH264_OK && !A.d_syms.alloc ((size_t)n_syms_total * sizeof (lh264_ctx_sym_t), false)) rc = LH264_E_HIP;
+  if (rc == LH264_OK) {
+    for (size_t j = 0; j < n_jobs; j++) { h_cj[j].syms_dev = A.d_syms.as<lh264_ctx_sym_t>(); h_cj[j].syms_cap = n_syms_total; h_kj[j].ctx_syms_dev = A.d_syms.as<lh264_ctx_sym_t>(); }
+    if (hipMemcpy (A.d_cj.p, h_cj.data(), n_jobs * sizeof (lh264_ctx_job_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy (A.d_kj.p, h_kj.data(), n_jobs * sizeof (lh264_code_job_t), hipMemcpyHostToDevice) != hipSuccess) rc = LH264_E_HIP;
+  }
+  if (rc == LH264_OK) rc = lh264_ctx_index_chains (A.d_cj.as<lh264_ctx_job_t>(), A.d_first.as<int32_t>(), n_chains, (int)n_jobs, max_mbs, nullptr);
   if (rc == LH264_OK) rc = lh264_code_chains (A.d_kj.as<lh264_code_job_t>(), A.d_first.as<int32_t>(), A.d_st.as<lh264_code_stream_t>(), n_chains, (int)n_jobs, (long long)n_mbs, max_mbs, nullptr);
   if (rc != LH264_OK || hipDeviceSynchronize() != hipSuccess) { fail_all (out, idx, rc != LH264_OK ? rc : LH264_E_HIP, "kernel launch failed"); return; }
   const double t_e = now_s();

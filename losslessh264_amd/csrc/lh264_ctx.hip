@@ -33,7 +33,26 @@ __device__ __forceinline__ int mb_type_code (int t) {       // MacroblockModel::
 }
 
 
-// ---- pass 1a: nonzero counts of every coded macroblock, all frames of all streams at once -----------------------------
+// position of raster coefficient i of a 4x4 / 8x8 block in scan order (the inverses of the zig-zag tables of pass 2), four to a word: a
+// lane holds four consecutive raster coefficients and takes its word with one load
+__constant__ uint32_t kInvZz16x4[4] = {0x06050100u, 0x0c070402u, 0x0d0b0803u, 0x0f0e0a09u};
+__constant__ uint32_t kInvZz64x4[16] = {0x10080100u, 0x0a030209u, 0x19201811u, 0x05040b12u, 0x211a130cu, 0x22293028u, 0x060d141bu, 0x1c150e07u, 0x38312a23u, 0x242b3239u, 0x170f161du, 0x332c251eu, 0x2d343b3au, 0x2e271f26u, 0x363d3c35u, 0x3f3e372fu};
+
+// lane exchanges inside quads / rows of 16 / the wave as DPP modifiers of a move (a __shfl_xor goes through the LDS crossbar)
+template <int CTRL> __device__ __forceinline__ int dpp_mov (int v) { return __builtin_amdgcn_mov_dpp (v, CTRL, 0xf, 0xf, true); }
+template <int CTRL, int ROWS> __device__ __forceinline__ int dpp_add0 (int x) { return __builtin_amdgcn_update_dpp (0, x, CTRL, ROWS, 0xf, false); }
+__device__ __forceinline__ int quad_max (int v) { v = max (v, dpp_mov<0xB1> (v)); return max (v, dpp_mov<0x4E> (v)); }       // quad_perm [1,0,3,2], [2,3,0,1]
+__device__ __forceinline__ int row16_max_of_quads (int v) { v = max (v, dpp_mov<0x124> (v)); return max (v, dpp_mov<0x128> (v)); }   // row_ror 4, 8
+__device__ __forceinline__ int wave_sum (int x) {          // the sum over the 64 lanes (in lane 63, read back to all)
+  x += dpp_add0<0x111, 0xf> (x); x += dpp_add0<0x112, 0xf> (x); x += dpp_add0<0x114, 0xf> (x); x += dpp_add0<0x118, 0xf> (x);
+  x += dpp_add0<0x142, 0xa> (x); x += dpp_add0<0x143, 0xc> (x);
+  return __builtin_amdgcn_readlane (x, 63);
+}
+
+// ---- pass 1a: nonzero counts of every coded macroblock, all frames of all streams at once; and HOW MANY symbols pass 2 will write
+// for it (the compact layout places a macroblock's symbols behind its predecessors': a running sum of these counts) -------------
+// symbols of a macroblock = 16 luma DC (Intra16x16) + 8 chroma DC (cbp chroma 1, 2) + per coded block 1 (its nonzero count) + the scan
+// positions from the block's first (0, or 1 where the DC went separately) to its last nonzero one (encode4x4, decode_slice.cpp:2059-2094)
 __global__ void __launch_bounds__ (256)
 ctx_nnz_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int blocks_per_job) {
   const int ji = blockIdx.x / blocks_per_job;
@@ -46,22 +65,65 @@ ctx_nnz_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int blocks
   // the macroblock type and the levels are requested together (one memory round trip, not two)
   const GLB int16_t* lv = as_glb<const int16_t> (J->levels_dev) + (size_t)k * 384;
   GLB uint8_t* cur = as_glb<uint8_t> (J->nnz_cur_dev) + (size_t)k * 24;
-  const int type_l = as_glb<const lh264_mb_t> (J->mbs_dev)[k].mb_type;
+  GLB uint16_t* nout = as_glb<uint16_t> (J->n_syms_dev) + k;
+  const GLB uint32_t* rec = (const GLB uint32_t*) (as_glb<const lh264_mb_t> (J->mbs_dev) + k);
+  const uint32_t head_l = rec[0], flags_l = rec[1];             // mb_type | cbp << 16 | qp << 24 ; qp_c | flags << 16 | intra_avail << 24
   const v2i a = * (const GLB v2i*) (lv + 4 * lane);
   v2i b = {0, 0};
   if (lane < 32) b = * (const GLB v2i*) (lv + 256 + 4 * lane);
   asm volatile ("" : : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));      // keeps the loads above the branch
-  const int type = __builtin_amdgcn_readfirstlane (type_l);
-  if (type == LH264_MB_SKIP || type == 0) return;       // inherited from PAST by pass 1b
-  int c = ((a.x & 0xffff) != 0) + ((a.x >> 16) != 0) + ((a.y & 0xffff) != 0) + ((a.y >> 16) != 0);
+  const uint32_t head = (uint32_t)__builtin_amdgcn_readfirstlane ((int)head_l);
+  const int type = head & 0xffff;
+  if (type == LH264_MB_SKIP || type == 0) { if (lane == 0) *nout = 0; return; }       // inherited from PAST by pass 1b; no symbols
+  if (((head >> 16) & 0xff) == 0 && type != LH264_MB_I16x16 && type != LH264_MB_IPCM) {
+    // nothing coded (cbp 0): every count is zero, there is no symbol (the levels were requested with the record: one round trip)
+    if (lane < 6) ((GLB uint32_t*)cur)[lane] = 0u;
+    if (lane == 0) *nout = 0;
+    return;
+  }
+  const int a0 = (a.x & 0xffff) != 0, a1 = (a.x >> 16) != 0, a2 = (a.y & 0xffff) != 0, a3 = (a.y >> 16) != 0;
+  const int b0 = (b.x & 0xffff) != 0, b1 = (b.x >> 16) != 0, b2 = (b.y & 0xffff) != 0, b3 = (b.y >> 16) != 0;
+  int c = a0 + a1 + a2 + a3;
   c += __shfl_xor (c, 1); c += __shfl_xor (c, 2);       // luma block = lane >> 2
-  int d = ((b.x & 0xffff) != 0) + ((b.x >> 16) != 0) + ((b.y & 0xffff) != 0) + ((b.y >> 16) != 0);
+  int d = b0 + b1 + b2 + b3;
   d += __shfl_xor (d, 1); d += __shfl_xor (d, 2);
   // gather the 24 counts into 6 dwords: lane 16*j + 4*i holds count 4*j + i
   const int c0 = __shfl (c, (lane & 3) * 16), c1 = __shfl (c, (lane & 3) * 16 + 4), c2 = __shfl (c, (lane & 3) * 16 + 8), c3 = __shfl (c, (lane & 3) * 16 + 12);
   const int d0 = __shfl (d, (lane & 1) * 16), d1 = __shfl (d, (lane & 1) * 16 + 4), d2 = __shfl (d, (lane & 1) * 16 + 8), d3 = __shfl (d, (lane & 1) * 16 + 12);
   if (lane < 4) ((GLB uint32_t*)cur)[lane] = (uint32_t)c0 | (uint32_t)c1 << 8 | (uint32_t)c2 << 16 | (uint32_t)c3 << 24;
   else if (lane < 6) ((GLB uint32_t*)cur)[lane] = (uint32_t)d0 | (uint32_t)d1 << 8 | (uint32_t)d2 << 16 | (uint32_t)d3 << 24;
+  // ---- the symbol count (same cases as ctx_symbols_kernel below) -------------------------------------------------------------------
+  if (type == LH264_MB_IPCM) { if (lane == 0) *nout = 0; return; }
+  const int cbp = (head >> 16) & 0xff, cbpl = cbp & 15, cbpc = cbp >> 4;
+  const bool t8 = (((uint32_t)__builtin_amdgcn_readfirstlane ((int)flags_l) >> 16) & LH264_MBF_T8x8) != 0;
+  const bool i16 = type == LH264_MB_I16x16, cdc = cbpc == 1 || cbpc == 2;
+  // luma: lane = 4 consecutive coefficients; 4x4: block lane >> 2 (z-order), raster 4 (lane & 3) + j; 8x8: block lane >> 4, raster 4 (lane & 15) + j
+  const int ls = i16 ? 1 : 0;                                   // first scan position of a luma block's coefficient symbols
+  // this lane's last nonzero scan position (-1: none).  Only raster coefficient 0 has scan position 0: where the DC went separately
+  // (ls == 1) it is the block's head lane that leaves its first coefficient out
+  const uint32_t pk4 = kInvZz16x4[lane & 3];
+  const bool lhead = t8 ? (lane & 15) == 0 : (lane & 3) == 0;   // one lane per block
+  int cnt = 0;
+  if (cbpl) {
+    const uint32_t pk = t8 ? kInvZz64x4[lane & 15] : pk4;
+    const int v0 = (a0 && !(ls && lhead)) ? (int) (pk & 0xffu) : -1, v1 = a1 ? (int) ((pk >> 8) & 0xffu) : -1,
+              v2 = a2 ? (int) ((pk >> 16) & 0xffu) : -1, v3 = a3 ? (int) (pk >> 24) : -1;
+    int last = max (max (v0, v1), max (v2, v3));
+    last = quad_max (last);
+    if (t8) last = row16_max_of_quads (last);
+    const bool lcoded = ((cbpl >> (lane >> 4)) & 1) != 0;      // the 8x8 quadrant of this lane's block (lane >> 4 either way)
+    cnt = (lcoded && lhead) ? 1 + (last >= ls ? last - ls + 1 : 0) : 0;
+  }
+  // chroma AC blocks (cbp chroma 2): lanes 0..31, block lane >> 2, their DC went separately
+  if (cbpc == 2) {
+    const bool chead = (lane & 3) == 0;
+    const int v0 = (b0 && !chead) ? (int) (pk4 & 0xffu) : -1, v1 = b1 ? (int) ((pk4 >> 8) & 0xffu) : -1,
+              v2 = b2 ? (int) ((pk4 >> 16) & 0xffu) : -1, v3 = b3 ? (int) (pk4 >> 24) : -1;
+    const int clast = quad_max (max (max (v0, v1), max (v2, v3)));
+    if (lane < 32 && chead) cnt += 1 + (clast >= 1 ? clast : 0);
+  }
+  cnt = wave_sum (cnt);
+  if (lane == 0) *nout = (uint16_t) (cnt + (i16 ? 16 : 0) + (cdc ? 8 : 0));
 }
 
 // ---- pass 1b: a skipped macroblock inherits the PAST entry (FreqImage semantics, decode_slice.cpp:3104-3108).  The only
@@ -147,6 +209,62 @@ __device__ __forceinline__ uint32_t nzmask16 (const int c[16]) {
   return m;
 }
 
+// ---- the compact layout: where each macroblock's symbols go ----------------------------------------------------------------------
+// ctx_offsets_kernel: one workgroup per picture - running sum of n_syms over its macroblocks -> sym_off_dev[k], the picture's total
+// ctx_bases_kernel:   one workgroup - running sum of the pictures' totals -> *sym_base_dev of every picture, the grand total
+__global__ void __launch_bounds__ (256)
+ctx_offsets_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, unsigned long long* __restrict__ job_total) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry;
+  const int ji = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (ji >= n_jobs) return;
+  const lh264_ctx_job_t* J = jobs + ji;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  if (!J->sym_off_dev) { if (tid == 0) job_total[ji] = 0; return; }
+  const int n = J->mb_w * J->mb_h;
+  const GLB uint16_t* ns = as_glb<const uint16_t> (J->n_syms_dev);
+  GLB uint32_t* off = as_glb<uint32_t> (J->sym_off_dev);
+  for (int k0 = 0; k0 < n; k0 += 256) {
+    const int k = k0 + tid;
+    const uint32_t v = k < n ? ns[k] : 0u;
+    uint32_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up ((int)incl, d); if (lane >= d) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = carry;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    if (k < n) off[k] = before + incl - v;
+    __syncthreads();
+    if (tid == 255) carry = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) job_total[ji] = carry;
+}
+__global__ void __launch_bounds__ (1024)
+ctx_bases_kernel (int n_jobs, unsigned long long* __restrict__ job_total, unsigned long long* __restrict__ total) {
+  __shared__ unsigned long long wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // every thread a run of consecutive pictures: its sum, the running sum over the threads, then the run again.  job_total[j] becomes
+  // the symbols in front of picture j (ctx_scatter_kernel hands them to the jobs)
+  const int per = (n_jobs + 1023) / 1024, j0 = min (tid * per, n_jobs), j1 = min (j0 + per, n_jobs);
+  unsigned long long mine = 0;
+  for (int j = j0; j < j1; j++) mine += job_total[j];
+  unsigned long long incl = mine;
+  for (int d = 1; d < 64; d <<= 1) { const unsigned long long t = (unsigned long long)__shfl_up ((long long)incl, d); if (lane >= d) incl += t; }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned long long at = incl - mine;
+  for (int w = 0; w < wave; w++) at += wsum[w];
+  for (int j = j0; j < j1; j++) { const unsigned long long v = job_total[j]; job_total[j] = at; at += v; }
+  if (tid == 1023) { job_total[n_jobs] = at; if (total) *total = at; }
+}
+__global__ void __launch_bounds__ (256)
+ctx_scatter_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, const unsigned long long* __restrict__ job_total) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n_jobs && jobs[j].sym_base_dev) *as_glb<unsigned long long> (jobs[j].sym_base_dev) = job_total[j];
+}
+
 __global__ void __launch_bounds__ (256)
 ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int blocks_per_job) {
   __shared__ CtxWave sm[4];
@@ -161,8 +279,13 @@ ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int bl
   const GLB lh264_mb_t* m = as_glb<const lh264_mb_t> (J->mbs_dev) + k;
   const GLB int16_t* lv = as_glb<const int16_t> (J->levels_dev) + (size_t)k * 384;
   const GLB uint8_t* cur = as_glb<const uint8_t> (J->nnz_cur_dev);
-  GLB uint64_t* out = (GLB uint64_t*) (as_glb<lh264_ctx_sym_t> (J->syms_dev) + (size_t)k * LH264_CTX_MAX_SYMS);
   GLB uint16_t* nout = as_glb<uint16_t> (J->n_syms_dev) + k;
+  // where the macroblock's symbols go: its fixed slot, or (compact layout) behind its predecessors' in the pool - the count pass has
+  // said how many there are (n_syms), the running sums where (sym_off, sym_base); a pool that is too small is not written to.
+  // (requested here with the other reads of the macroblock, looked at when the symbols are copied out)
+  const bool compact = J->sym_off_dev != nullptr;
+  unsigned long long sym_base_v = 0; uint32_t sym_off_v = 0, n_syms_v = 0;
+  if (compact) { sym_base_v = *as_glb<const unsigned long long> (J->sym_base_dev); sym_off_v = as_glb<const uint32_t> (J->sym_off_dev)[k]; n_syms_v = *nout; }
 
   // Every global read of the macroblock is issued before anything is looked at: the record (lanes 0..7 take a dword each),
   // the levels and the four nnz entries travel together, one memory round trip instead of a chain of three (a wave has
@@ -190,6 +313,7 @@ ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int bl
     if (lane == 0) *nout = 0;
     return;
   }
+
   const int cbp = (head >> 16) & 0xff;
   const int t8 = (__builtin_amdgcn_readlane ((int)rec, 1) >> 16) & LH264_MBF_T8x8;                 // flags: byte 6
   const int sid = (int) ((uint32_t)__builtin_amdgcn_readlane ((int)rec, 6) >> 16);                // slice_id: bytes 26..27
@@ -286,8 +410,15 @@ ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int bl
   }
   asm volatile ("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < total; i += 64) out[i] = W.osym[i];
-  if (lane == 0) *nout = (uint16_t)total;
+  GLB uint64_t* out;
+  bool room = true;
+  if (compact) {
+    const unsigned long long at = sym_base_v + sym_off_v;
+    room = at + n_syms_v <= J->syms_cap && (int)n_syms_v == total;
+    out = (GLB uint64_t*) (as_glb<lh264_ctx_sym_t> (J->syms_dev) + at);
+  } else out = (GLB uint64_t*) (as_glb<lh264_ctx_sym_t> (J->syms_dev) + (size_t)k * LH264_CTX_MAX_SYMS);
+  if (room) for (int i = lane; i < total; i += 64) out[i] = W.osym[i];
+  if (lane == 0 && (!compact || !room)) *nout = room ? (uint16_t)total : (uint16_t)0;       // (compact layout: the count pass has written it)
 }
 
 }  // namespace lh264

@@ -25,7 +25,7 @@ def test_library_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), "missing export " + n
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib().lh264_abi_version() == 2
+    assert _lib.lib().lh264_abi_version() == 3
 
 
 def test_record_layouts_match_header():
