@@ -582,9 +582,13 @@ def main():
                        "stages_in_timed_region": "a1-a7 (IDCT, intra/inter prediction, deblocking, reference padding) + a8 (context-model prior index per "
                                                  "coefficient symbol) + a9/a10 (binarisation, adaptive probabilities, bool coders): the whole compress direction "
                                                  "on the device, records in HBM -> tagged byte streams in HBM; the host CAVLC/CABAC parse is not in this step",
-                       "parallelism": "reconstruct: one workgroup per stream, one wave per MB row; coder: a thread per symbol (binarise), one workgroup per "
-                                      "stream (adaptive probabilities), one lane per (stream, tag) (bool coder's range), one lane per 256 decisions (its sums); "
-                                      "the reconstruct kernel runs on a second HIP stream beside the context-index and coder kernels; streams sharded across GPUs",
+                       "parallelism": "reconstruct: one workgroup per stream, one wave per MB row; context indices: a wave per macroblock (compact symbol pool); "
+                                      "coder, chosen per call: many small streams - a thread per symbol (binarise), one workgroup per stream (adaptive "
+                                      "probabilities); few large streams - a lane per decision into per-partition runs, one wave per (stream, partition); then for "
+                                      "both the bool coders: range walk in coarse chunks from checked candidate start states, one lane per 256 decisions (sums), "
+                                      "one wave per (stream, tag) (carries); the reconstruct kernel runs on a second HIP stream beside the context-index and coder "
+                                      "kernels; streams sharded across GPUs",
+                       "coder_form": ("stream per workgroup" if n_local >= 384 and sess.n_mbs_total / max(1, n_local) <= 12288 else "wave per (stream, partition)"),
                        "stage_ms_note": "stage times are from steps run on one stream; in the timed steps the stages overlap, ms_per_step is less than their sum",
                        "pipeline": ("two batches in flight: the context-index kernels (row a8) of the next batch run on a third HIP stream beside the second half of "
                                     "this batch's coder; every step launches every kernel of rows a1-a10 once" if pipeline else "none: every batch on its own"),
@@ -593,6 +597,7 @@ def main():
                        "a1_a8_only_MB_per_s": local_bytes / (a18 * 1e-3) / 1e6,
                        "compression": roundtrip, "parity_checked": checked, "mixed_batch": mixed, "host_stages": host_stages,
                        "multi_gpu": {"result_records_gathered": n_records, "global_streams": n_global, "collectives": collectives,
+                                     "work_list": "no scatter: every rank derives its share of the global stream list locally (partition_by_work); one gather of result records",
                                      "measured_on_hardware": ("rehearsal: all ranks on GPU 0, gloo collectives - not a scaling measurement" if rehearse
                                                               else "this line" if world > 1 else "single GPU; N > 1 unmeasured in this run")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
