@@ -111,6 +111,17 @@ template <class S> __device__ __forceinline__ void bz_tree (S& s, uint32_t prior
     off += bit ? 1u + ((1u << (n - 1)) - 1u) : 1u;
   }
 }
+// the tag of a coefficient / nonzero-count symbol: the context-index kernel leaves it in the symbol's pad byte (lh264_ctx.hip mk_sym);
+// symbols from elsewhere (pad 0) have it taken out of the prior: colour, first scan position and macroblock class (encode4x4)
+__device__ __forceinline__ int ac_tag_base (uint32_t prior, int kind, int pad) {
+  if (pad) return pad;
+  const uint32_t nco = kind == LH264_SYM_AC4 ? 16u : 64u;
+  const uint32_t outer = prior / 3125u;
+  const int emitted = (int) (outer % nco), color = (int) ((outer / nco) % 3u), code = (int) ((outer / nco / 3u) % 16u);
+  const int first = color == 0 && emitted == 0 && code != 1;
+  return color ? 29 : (first ? 19 : 24);
+}
+__device__ __forceinline__ int nz_tag (uint32_t prior, int pad) { return pad ? pad : (((prior / 27u) % 3u) ? 29 : 19); }
 template <class S> __device__ __forceinline__ void binarize (S& s, uint32_t prior, int value, int kind, int pad) {
   enum { T_LDC = 17, T_CRDC = 18, T_LAC_0_EOB = 19, T_LAC_N_EOB = 24, T_CRAC_EOB = 29 };
   const int table = (int) (prior >> 27);
@@ -122,16 +133,12 @@ template <class S> __device__ __forceinline__ void binarize (S& s, uint32_t prio
     bz_int (s, value, 7, 8, 0, 3, 3, 4, 0, t, t, t, t);
     break; }
   case LH264_SYM_NZ4: case LH264_SYM_NZ8: {                 // UnsignedIntPrior<3,4>
-    const int t = ((prior / 27u) % 3u) ? T_CRAC_EOB : T_LAC_0_EOB;
+    const int t = nz_tag (prior, pad);
     s.cell (LH264_PRIOR (kind == LH264_SYM_NZ4 ? LH264_TB_NZ4 : LH264_TB_NZ8, prior));
     bz_int (s, value, 7, -1, 0, 3, 3, 4, 0, t, t, t, t);
     break; }
   case LH264_SYM_AC4: case LH264_SYM_AC8: {                 // UEGkIntPrior<14,4,2,4,0>; tags by colour / first scan position (encode4x4)
-    const uint32_t nco = kind == LH264_SYM_AC4 ? 16u : 64u;
-    const uint32_t outer = prior / 3125u;
-    const int emitted = (int) (outer % nco), color = (int) ((outer / nco) % 3u), code = (int) ((outer / nco / 3u) % 16u);
-    const int first = color == 0 && emitted == 0 && code != 1;
-    const int base = color ? T_CRAC_EOB : (first ? T_LAC_0_EOB : T_LAC_N_EOB);
+    const int base = ac_tag_base (prior, kind, pad);
     s.touch (base + 2);                                      // encode4x4 bills to tag(..._EXP): the stream exists from then on
     s.cell (LH264_PRIOR (kind == LH264_SYM_AC4 ? LH264_TB_AC4 : LH264_TB_AC8, prior));
     bz_uegk (s, value, 14, 4, 2, 4, 0, base + 2, base + 3, base + 1, base + 4);
@@ -201,18 +208,14 @@ __device__ __forceinline__ SymCount sym_count (uint32_t prior, int value, int ki
     c.key = mvd ? prior : LH264_PRIOR (kind == LH264_SYM_LUMA_DC ? LH264_TB_LDC : kind == LH264_SYM_CHROMA_DC ? LH264_TB_CDC : kind == LH264_SYM_NZ4 ? LH264_TB_NZ4 :
                                        kind == LH264_SYM_NZ8 ? LH264_TB_NZ8 : kind == LH264_SYM_AC4 ? LH264_TB_AC4 : LH264_TB_AC8, prior);
     if (ac) {                                                   // tags by colour / first scan position (encode4x4)
-      const uint32_t nco = kind == LH264_SYM_AC4 ? 16u : 64u;
-      const uint32_t outer = prior / 3125u;
-      const int emitted = (int) (outer % nco), color = (int) ((outer / nco) % 3u), code = (int) ((outer / nco / 3u) % 16u);
-      const int first = color == 0 && emitted == 0 && code != 1;
-      const int base = color ? T_CRAC_EOB : (first ? T_LAC_0_EOB : T_LAC_N_EOB);
+      const int base = ac_tag_base (prior, kind, pad);
       c.tch = tag_slot (base + 2);
       c.s0 = tag_slot (base + 1); c.n0 = nz;
       if (ns) { c.s1 = tag_slot (base + 4); c.n1 = ns; }
       if (nm) { c.s2 = tag_slot (base + 3); c.n2 = nm; }
       if (ne) { c.s3 = tag_slot (base + 2); c.n3 = ne; }
     } else {
-      c.s0 = tag_slot (mvd ? pad : kind == LH264_SYM_LUMA_DC ? T_LDC : kind == LH264_SYM_CHROMA_DC ? T_CRDC : (((prior / 27u) % 3u) ? T_CRAC_EOB : T_LAC_0_EOB));
+      c.s0 = tag_slot (mvd ? pad : kind == LH264_SYM_LUMA_DC ? T_LDC : kind == LH264_SYM_CHROMA_DC ? T_CRDC : nz_tag (prior, pad));
       c.n0 = c.n;
     }
     return c;
@@ -271,18 +274,14 @@ __device__ __forceinline__ Decision decision_at (uint32_t prior, int value, int 
   switch (kind) {
   case LH264_SYM_LUMA_DC: case LH264_SYM_CHROMA_DC: case LH264_SYM_NZ4: case LH264_SYM_NZ8: {      // IntPrior<3,4> / UnsignedIntPrior<3,4>
     const bool dc = kind == LH264_SYM_LUMA_DC || kind == LH264_SYM_CHROMA_DC;
-    d.tag = kind == LH264_SYM_LUMA_DC ? T_LDC : kind == LH264_SYM_CHROMA_DC ? T_CRDC : (((prior / 27u) % 3u) ? T_CRAC_EOB : T_LAC_0_EOB);
+    d.tag = kind == LH264_SYM_LUMA_DC ? T_LDC : kind == LH264_SYM_CHROMA_DC ? T_CRDC : nz_tag (prior, pad);
     d.key = LH264_PRIOR (kind == LH264_SYM_LUMA_DC ? LH264_TB_LDC : kind == LH264_SYM_CHROMA_DC ? LH264_TB_CDC : kind == LH264_SYM_NZ4 ? LH264_TB_NZ4 : LH264_TB_NZ8, prior);
     if (j == 0) { d.place = 7; d.bit = value == 0; break; }
     if (dc && j == 1) { d.place = 8; d.bit = value > 0; break; }
     int_tail_at (d, j - (dc ? 2 : 1), value < 0 ? -value : value, 0, 0, 3, 3, d.tag, d.tag);
     break; }
   case LH264_SYM_AC4: case LH264_SYM_AC8: {                 // UEGkIntPrior<14,4,2,4,0>; tags by colour / first scan position (encode4x4)
-    const uint32_t nco = kind == LH264_SYM_AC4 ? 16u : 64u;
-    const uint32_t outer = prior / 3125u;
-    const int emitted = (int) (outer % nco), color = (int) ((outer / nco) % 3u), code = (int) ((outer / nco / 3u) % 16u);
-    const int first = color == 0 && emitted == 0 && code != 1;
-    const int base = color ? T_CRAC_EOB : (first ? T_LAC_0_EOB : T_LAC_N_EOB);
+    const int base = ac_tag_base (prior, kind, pad);
     d.key = LH264_PRIOR (kind == LH264_SYM_AC4 ? LH264_TB_AC4 : LH264_TB_AC8, prior);
     uegk_at (d, j, value, 14, 2, 0, base + 2, base + 3, base + 1, base + 4);
     break; }

@@ -168,9 +168,9 @@ constexpr uint8_t cZz64[64] = {
   10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63
 };
 
-__device__ __forceinline__ uint64_t mk_sym (uint32_t prior, int value, int kind) {
-  // {u32 prior, i16 value, u8 kind, u8 pad}
-  return (uint64_t)prior | ((uint64_t) (uint16_t)value << 32) | ((uint64_t) (uint8_t)kind << 48);
+__device__ __forceinline__ uint64_t mk_sym (uint32_t prior, int value, int kind, int tag) {
+  // {u32 prior, i16 value, u8 kind, u8 pad}; pad: the symbol's (first) tag, so that the coder does not have to take the prior apart again
+  return (uint64_t)prior | ((uint64_t) (uint16_t)value << 32) | ((uint64_t) (uint8_t)kind << 48) | ((uint64_t) (uint8_t)tag << 56);
 }
 __device__ __forceinline__ int min2 (int v) { return v < 2 ? v : 2; }
 __device__ __forceinline__ int clamp04 (int v) { return v < 0 ? 0 : (v > 4 ? 4 : v); }
@@ -188,14 +188,14 @@ struct WalkState { int left_nz, prev, prev2, emitted; };
 // up to the last nonzero one is a symbol whose prior depends on the two previous levels and the nonzeros left
 // wmax: the largest `last` of the wave (uniform): positions beyond it are skipped four at a time without being looked at
 template <int CH>
-__device__ __forceinline__ void walk16 (const int c[16], int start, int last, int wmax, uint32_t outer0, int kind, WalkState& w, LDS uint64_t* dst) {
+__device__ __forceinline__ void walk16 (const int c[16], int start, int last, int wmax, uint32_t outer0, int kind, int tag0, int tagn, WalkState& w, LDS uint64_t* dst) {
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     const int pos = CH * 16 + i;
     if ((i & 3) == 0 && wmax < pos) return;
     if (pos >= start && pos <= last) {
       const uint32_t inner = (uint32_t) ((((min (4, w.left_nz) * 5 + clamp04 (w.prev + 2)) * 5 + clamp04 (w.prev2 + 2)) * 5 + 2) * 5 + 2);
-      dst[w.emitted] = mk_sym ((outer0 + w.emitted) * 3125u + inner, c[i], kind);
+      dst[w.emitted] = mk_sym ((outer0 + w.emitted) * 3125u + inner, c[i], kind, w.emitted ? tagn : tag0);
       w.prev2 = w.prev; w.prev = c[i]; w.emitted++;
       if (c[i]) w.left_nz--;
     }
@@ -386,26 +386,27 @@ ctx_symbols_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, int bl
     LDS uint64_t* dst = W.osym + my_off;
     const int nco = big ? 64 : 16;
     dst[0] = mk_sym ((uint32_t) ((((((st * 16 + mbc) * 3 + color) * 3 + min2 (past)) * 3 + min2 (left)) * 3) + min2 (above)), nonzeros,
-                     big ? LH264_SYM_NZ8 : LH264_SYM_NZ4);
+                     big ? LH264_SYM_NZ8 : LH264_SYM_NZ4, color ? 29 : 19);
+    const int tagn = color ? 29 : 24, tag0 = (color || mbc == 1) ? tagn : 19;      // encode4x4's tags: chroma / the first luma coefficient / the others
     const uint32_t outer0 = (uint32_t) (((st * 16 + mbc) * 3 + color) * nco);
     WalkState w = {nonzeros, 0, 0, 0};
-    if (!big) walk16<0> (c, start, last, wmax, outer0, LH264_SYM_AC4, w, dst + 1);
+    if (!big) walk16<0> (c, start, last, wmax, outer0, LH264_SYM_AC4, tag0, tagn, w, dst + 1);
     else {
-      load_scan16<64, 0> (ac, c); walk16<0> (c, start, last, wmax, outer0, LH264_SYM_AC8, w, dst + 1);
-      load_scan16<64, 1> (ac, c); walk16<1> (c, start, last, wmax, outer0, LH264_SYM_AC8, w, dst + 1);
-      load_scan16<64, 2> (ac, c); walk16<2> (c, start, last, wmax, outer0, LH264_SYM_AC8, w, dst + 1);
-      load_scan16<64, 3> (ac, c); walk16<3> (c, start, last, wmax, outer0, LH264_SYM_AC8, w, dst + 1);
+      load_scan16<64, 0> (ac, c); walk16<0> (c, start, last, wmax, outer0, LH264_SYM_AC8, tag0, tagn, w, dst + 1);
+      load_scan16<64, 1> (ac, c); walk16<1> (c, start, last, wmax, outer0, LH264_SYM_AC8, tag0, tagn, w, dst + 1);
+      load_scan16<64, 2> (ac, c); walk16<2> (c, start, last, wmax, outer0, LH264_SYM_AC8, tag0, tagn, w, dst + 1);
+      load_scan16<64, 3> (ac, c); walk16<3> (c, start, last, wmax, outer0, LH264_SYM_AC8, tag0, tagn, w, dst + 1);
     }
   }
   if (lane >= 32 && lane < 48) {
     if (i16) {                                       // getLumaDCIntPrior: lumaDCIntPriors[i][slice][mbtype]
       const int i = lane - 32;
-      W.osym[i] = mk_sym ((uint32_t) ((i * 5 + st) * 16 + mbc), W.lv[i * 16], LH264_SYM_LUMA_DC);
+      W.osym[i] = mk_sym ((uint32_t) ((i * 5 + st) * 16 + mbc), W.lv[i * 16], LH264_SYM_LUMA_DC, 17);
     }
   } else if (lane >= 48 && lane < 56) {
     if (cdc) {
       const int i = lane - 48;
-      W.osym[ndc_l + i] = mk_sym ((uint32_t) ((i * 5 + st) * 16 + mbc), W.lv[256 + i * 16], LH264_SYM_CHROMA_DC);
+      W.osym[ndc_l + i] = mk_sym ((uint32_t) ((i * 5 + st) * 16 + mbc), W.lv[256 + i * 16], LH264_SYM_CHROMA_DC, 18);
     }
   }
   asm volatile ("" ::: "memory");
