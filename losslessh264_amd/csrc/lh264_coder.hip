@@ -181,13 +181,14 @@ template <class S> __device__ __forceinline__ void binarize (S& s, uint32_t prio
 // emitInt / emitUEGkInt with different constants) go through ONE instruction stream with the constants in registers, not through a
 // branch per kind (round-3 counters: 19 of 64 lanes were active on average in the per-kind version).
 struct SymCount { int n, s0, s1, s2, s3, n0, n1, n2, n3, tch, raws; uint32_t key; };
-__device__ __forceinline__ SymCount sym_count (uint32_t prior, int value, int kind, int pad) {
+template <bool CTX_ONLY = false> __device__ __forceinline__ SymCount sym_count (uint32_t prior, int value, int kind, int pad) {
   enum { T_LDC = 17, T_CRDC = 18, T_LAC_0_EOB = 19, T_LAC_N_EOB = 24, T_CRAC_EOB = 29 };
   SymCount c; c.n = 0; c.s0 = c.s1 = c.s2 = c.s3 = -1; c.n0 = c.n1 = c.n2 = c.n3 = 0; c.tch = -1; c.raws = 0; c.key = prior;
   const int table = (int) (prior >> 27);
-  const bool ac = kind == LH264_SYM_AC4 || kind == LH264_SYM_AC8, mvd = kind == LH264_SYM_MVD;
+  // CTX_ONLY: the symbol is known to come from the context-index kernel (a coefficient, a nonzero count or a DC level)
+  const bool ac = kind == LH264_SYM_AC4 || kind == LH264_SYM_AC8, mvd = !CTX_ONLY && kind == LH264_SYM_MVD;
   const bool dc = kind == LH264_SYM_LUMA_DC || kind == LH264_SYM_CHROMA_DC, nzk = kind == LH264_SYM_NZ4 || kind == LH264_SYM_NZ8;
-  if (ac || mvd || dc || nzk) {
+  if (CTX_ONLY || ac || mvd || dc || nzk) {
     // [zero flag] [sign] [unary up to N ones; beyond it: zero flag of the escape] [emitInt tail: l2 + 1 exponent, l2 + order mantissa decisions]
     const int N = ac ? 14 : mvd ? 9 : 0, order = mvd ? 3 : 0;
     const int av = value < 0 ? -value : value;
@@ -226,6 +227,9 @@ __device__ __forceinline__ SymCount sym_count (uint32_t prior, int value, int ki
         kind == LH264_SYM_TREE ? (table == LH264_TB_SKIPRUN ? 9 : table == LH264_TB_SUBMB ? 8 : table == LH264_TB_CBPC ? 2 : 4) :
         kind == LH264_SYM_POW2 ? 1 + ((unsigned) (uint16_t)value != preferred ? (qpl ? 7 : 3) : 0) : 0;
   if (kind == LH264_SYM_RAW) { c.raws = c.n; c.key = CODER_RAW_KEY; }
+  // trees over several cells: the first cell (cell_part gives all of them the same partition)
+  if (kind == LH264_SYM_TREE && (table == LH264_TB_SKIPRUN || table == LH264_TB_SUBMB)) c.key = (prior & 0xf8000000u) | ((prior & 0x7ffffffu) << (table == LH264_TB_SKIPRUN ? 5 : 4));
+  if (kind == LH264_SYM_POW2 && qpl) c.key = (prior & 0xf8000000u) | ((prior & 0x7ffffffu) << 3);
   if (c.n > 0) { c.s0 = tag_slot (pad); c.n0 = c.n; }          // the host's symbols name their tag
   return c;
 }
@@ -307,7 +311,14 @@ __device__ __forceinline__ Decision decision_at (uint32_t prior, int value, int 
   return d;
 }
 // which of the stream's P partitions (a power of two) the DynProbs of a cell belong to: every partition is resolved by a wave of its own
-__device__ __forceinline__ uint32_t cell_part (uint32_t key, int log2p) { return log2p ? ((key ^ (key >> 15)) * 0x2C1B3C6Du) >> (32 - log2p) : 0u; }
+// The cells a Branch tree spreads over (skip run: 32, sub-macroblock type: 16, the QP delta: 8 cells per prior, tree_at) share the partition
+// of the tree's prior: every symbol then has all its modelled decisions in ONE partition (and its raw bits in TEST_PROB's).
+__device__ __forceinline__ uint32_t cell_part (uint32_t key, int log2p) {
+  const uint32_t table = key >> 27;
+  const uint32_t sh = table == LH264_TB_SKIPRUN ? 5u : table == LH264_TB_SUBMB ? 4u : table == LH264_TB_QPL ? 3u : 0u;
+  const uint32_t k = (key & 0xf8000000u) | ((key & 0x7ffffffu) >> sh);
+  return log2p ? ((k ^ (k >> 15)) * 0x2C1B3C6Du) >> (32 - log2p) : 0u;
+}
 
 // a decision word (64 bits), as the binarisation leaves it for the resolve kernel: bits 0..31 the key of the DynProb's cell (LH264_PRIOR
 // form; CODER_RAW_KEY: the shared TEST_PROB), 32..35 the place in the cell, 36 the bit, 37..63 the entry of the stream's tag lists the
@@ -489,32 +500,69 @@ coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* _
   unsigned long long touch = 0;
   const int P = 1 << log2p;
   const uint32_t praw = cell_part (CODER_RAW_KEY, log2p);
+  auto account = [&] (const SymCount c) {
+    if (c.s0 >= 0) add (c.s0, (uint32_t)c.n0);
+    if (c.s1 >= 0) add (c.s1, (uint32_t)c.n1);
+    if (c.s2 >= 0) add (c.s2, (uint32_t)c.n2);
+    if (c.s3 >= 0) add (c.s3, (uint32_t)c.n3);
+    if (c.tch >= 0) touch |= 1ull << c.tch;
+    add (LH264_N_TAG_SLOTS, (uint32_t)c.n);
+    // partitions: the symbol's cell, TEST_PROB's for its raw bits
+    if (c.raws) padd (praw, (uint32_t)c.raws);
+    if (c.n > c.raws) padd (cell_part (c.key, log2p), (uint32_t) (c.n - c.raws));
+  };
+  // Counting does not need the coding order.  With the compact pool the segment's symbols are two dense ranges - the host's lists and
+  // the context-index kernel's symbols - which are swept with coalesced loads (no search for the macroblock of a symbol).  Not so:
+  // fixed slots per macroblock, a pool with gaps, or coefficient symbols of a macroblock whose host list has no marker (they are not coded).
+  bool dense = S.J->ctx_sym_off_dev != 0;
+  uint32_t off0 = 0, nctx = 0;
+  if (dense) {
+    const GLB uint32_t* so = glb<const uint32_t> (S.J->ctx_sym_off_dev) + S.k0;
+    const uint32_t myoff = lane < S.n ? so[lane] : 0u, mymc = lane < S.n ? (uint32_t)L.seg.mc[lane] : 0u;
+    const uint32_t nextoff = (uint32_t)__shfl_down ((int)myoff, 1);
+    const bool bad = lane < S.n && ((mymc != 0u && L.seg.p[lane] == 0xffffu) || (lane + 1 < S.n && myoff + mymc != nextoff));
+    dense = __ballot (bad) == 0ull;
+    off0 = (uint32_t)__builtin_amdgcn_readfirstlane ((int)myoff);
+    nctx = (uint32_t)__builtin_amdgcn_readlane ((int) (myoff + mymc), S.n - 1) - off0;
+  }
+  if (dense) {
+    const GLB uint64_t* hs = glb<const uint64_t> (S.J->syn_syms_dev) + L.seg.hoff[0];
+    const uint32_t nh = L.seg.hoff[S.n] - L.seg.hoff[0];
+    for (uint32_t i0 = 0; i0 < nh; i0 += 256u) {
+      uint64_t sy[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const uint32_t i = i0 + 64u * (uint32_t)q + (uint32_t)lane; sy[q] = i < nh ? hs[i] : 0ull; }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t prior = (uint32_t)sy[q], hi = (uint32_t) (sy[q] >> 32);
+        const int kind = (int) ((hi >> 16) & 0xffu);
+        if (i0 + 64u * (uint32_t)q + (uint32_t)lane >= nh || kind == LH264_SYM_SPLICE) continue;
+        account (sym_count (prior, (int) (int16_t) (hi & 0xffffu), kind, (int) (hi >> 24)));
+      }
+    }
+    const GLB uint64_t* cs = glb<const uint64_t> (S.J->ctx_syms_dev) + (size_t)*glb<const unsigned long long> (S.J->ctx_sym_base_dev) + off0;
+    for (uint32_t i0 = 0; i0 < nctx; i0 += 256u) {
+      uint64_t sy[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const uint32_t i = i0 + 64u * (uint32_t)q + (uint32_t)lane; sy[q] = i < nctx ? cs[i] : 0ull; }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t prior = (uint32_t)sy[q], hi = (uint32_t) (sy[q] >> 32);
+        if (i0 + 64u * (uint32_t)q + (uint32_t)lane >= nctx) continue;
+        account (sym_count<true> (prior, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24)));
+      }
+    }
+  } else
   for (uint32_t s0 = 0; s0 < S.total; s0 += 256u) {
-    // four symbols per lane and step: their loads are under way together
+    // in coding order, four symbols per lane and step: their loads are under way together
     uint64_t sy[4];
     seg_symbol4 (L.seg, S, s0, lane, sy);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const uint64_t sym = sy[q];
       const uint32_t prior = (uint32_t)sym, hi = (uint32_t) (sym >> 32);
-      const int value = (int) (int16_t) (hi & 0xffffu), kind = (int) ((hi >> 16) & 0xffu), pad = (int) (hi >> 24);
       if (s0 + 64u * (uint32_t)q + (uint32_t)lane >= S.total) continue;
-      const SymCount c = sym_count (prior, value, kind, pad);
-      if (c.s0 >= 0) add (c.s0, (uint32_t)c.n0);
-      if (c.s1 >= 0) add (c.s1, (uint32_t)c.n1);
-      if (c.s2 >= 0) add (c.s2, (uint32_t)c.n2);
-      if (c.s3 >= 0) add (c.s3, (uint32_t)c.n3);
-      if (c.tch >= 0) touch |= 1ull << c.tch;
-      add (LH264_N_TAG_SLOTS, (uint32_t)c.n);
-      // partitions: the symbol's cell, TEST_PROB's for its raw bits; a tree over several cells is walked
-      const int table = (int) (prior >> 27);
-      const bool multi = (kind == LH264_SYM_TREE && (table == LH264_TB_SKIPRUN || table == LH264_TB_SUBMB)) || (kind == LH264_SYM_POW2 && table == LH264_TB_QPL);
-      if (multi) {
-        for (int j = 0; j < c.n; j++) padd (cell_part (decision_at (prior, value, kind, pad, j).key, log2p), 1u);
-      } else if (c.n > 0) {
-        if (c.raws) padd (praw, (uint32_t)c.raws);
-        if (c.n > c.raws) padd (cell_part (c.key, log2p), (uint32_t) (c.n - c.raws));
-      }
+      account (sym_count (prior, (int) (int16_t) (hi & 0xffffu), (int) ((hi >> 16) & 0xffu), (int) (hi >> 24)));
     }
   }
   wsync();
