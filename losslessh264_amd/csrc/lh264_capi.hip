@@ -25,11 +25,14 @@ __global__ void ctx_offsets_kernel (const lh264_ctx_job_t* jobs, int n_jobs, uns
 __global__ void ctx_bases_kernel (int n_jobs, unsigned long long* job_total, unsigned long long* total);
 __global__ void ctx_scatter_kernel (const lh264_ctx_job_t* jobs, int n_jobs, const unsigned long long* job_total);
 __global__ void coder_jobs_kernel (const lh264_code_job_t* jobs, const int32_t* chain_first, int n_jobs, int n_chains, unsigned seg_bound, uint32_t* seg0, uint32_t* seg_job, uint32_t* job_chain, uint32_t* chain_info);
-__global__ void coder_count_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* seg_job, int n_jobs, int log2p, uint32_t* seg_cnt, uint32_t* seg_part);
+__global__ void coder_count_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* seg_job, int n_jobs, uint32_t* seg_cnt, uint32_t* seg_bkt);
+__global__ void coder_balance_kernel (const uint32_t* seg0, const int32_t* chain_first, const uint32_t* seg_bkt, int n_chains, int log2p, uint8_t* chain_map);
+__global__ void coder_partoff_kernel (const uint32_t* seg0, const uint32_t* seg_job, const uint32_t* job_chain, int n_jobs, int log2p, const uint32_t* seg_bkt,
+                                      const uint8_t* chain_map, uint32_t* seg_part);
 __global__ void coder_scan_kernel (const uint32_t* seg0, const int32_t* chain_first, uint32_t* seg_cnt, uint32_t* seg_doff, uint32_t* chain_info, int n_chains);
 __global__ void coder_bases_kernel (uint32_t* chain_info, int n_chains, unsigned long long* totals);
 __global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* seg_job, const uint32_t* job_chain, int n_jobs, int log2p,
-                                   const uint32_t* seg_doff, const uint32_t* seg_cnt, const uint32_t* seg_part, const uint32_t* chain_info, uint64_t* D);
+                                   const uint32_t* seg_doff, const uint32_t* seg_cnt, const uint32_t* seg_part, const uint8_t* chain_map, const uint32_t* chain_info, uint64_t* D);
 __global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint32_t* seg0, const int32_t* chain_first,
                                       const uint32_t* seg_doff, const uint32_t* seg_part, const uint64_t* D, uint16_t* Q, int n_chains, int log2p);
 __global__ void coder_chunkmap_kernel (const uint32_t* chain_info, int n_pairs, uint32_t* pair_chunk0, uint32_t* pair_coarse0);
@@ -318,12 +321,14 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   const size_t o_seg0 = 0, o_jobchain = up256 ((size_t) (n_jobs + 1) * 4), o_info = o_jobchain + up256 ((size_t) (n_jobs + 1) * 4),
                o_totals = o_info + up256 ((size_t)n_chains * LH264_CODER_INFO_WORDS * 4), o_doff = o_totals + 256,
                o_sjob = o_doff + up256 (seg_bound * 4 + 4), o_cnt = o_sjob + up256 (seg_bound * 4 + 4), o_part = o_cnt + up256 (seg_bound * LH264_CODER_CNT_STRIDE * 4 + 4),
-               small_need = o_part + up256 (sw ? 4 : seg_bound * pstride * 4 + 4);
+               o_bkt = o_part + up256 (sw ? 4 : seg_bound * pstride * 4 + 4), o_map = o_bkt + up256 (sw ? 4 : seg_bound * LH264_CODER_MAX_PARTS * 4),
+               small_need = o_map + up256 ((size_t)n_chains * LH264_CODER_MAX_PARTS);
   if (int rc = grow (&W.small, &W.small_cap, small_need)) return rc;
   uint8_t* sm = (uint8_t*)W.small;
   uint32_t* seg0 = (uint32_t*) (sm + o_seg0); uint32_t* job_chain = (uint32_t*) (sm + o_jobchain); uint32_t* info = (uint32_t*) (sm + o_info);
   unsigned long long* totals = (unsigned long long*) (sm + o_totals); uint32_t* seg_doff = (uint32_t*) (sm + o_doff); uint32_t* seg_cnt = (uint32_t*) (sm + o_cnt);
   uint32_t* seg_part = (uint32_t*) (sm + o_part); uint32_t* seg_job = (uint32_t*) (sm + o_sjob);
+  uint32_t* seg_bkt = (uint32_t*) (sm + o_bkt); uint8_t* chain_map = sm + o_map;     // decisions per bucket of cells; bucket -> partition
   const unsigned seg_blocks = (unsigned) ((seg_bound + 3) / 4);
   if (sw) {
     hipLaunchKernelGGL (lh264sw::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, seg0, job_chain, info);
@@ -340,7 +345,14 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
     hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, (unsigned)seg_bound, seg0, seg_job, job_chain, info);
     HIPCHK (hipGetLastError());
     if (n_jobs > 0 && total_mbs > 0) {
-      hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, n_jobs, log2p, seg_cnt, seg_part);
+      hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, n_jobs, seg_cnt, seg_bkt);
+      HIPCHK (hipGetLastError());
+    }
+    // the stream's partitions: its buckets of cells dealt out evenly; then where each partition's run starts in every segment
+    hipLaunchKernelGGL (lh264::coder_balance_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_bkt, n_chains, log2p, chain_map);
+    HIPCHK (hipGetLastError());
+    if (n_jobs > 0 && total_mbs > 0) {
+      hipLaunchKernelGGL (lh264::coder_partoff_kernel, dim3 (seg_blocks), dim3 (256), 0, st, seg0, seg_job, job_chain, n_jobs, log2p, seg_bkt, chain_map, seg_part);
       HIPCHK (hipGetLastError());
     }
     hipLaunchKernelGGL (lh264::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_cnt, seg_doff, info, n_chains);
@@ -376,7 +388,7 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   HIPCHK (hipMemsetAsync (acc, 0, n_acc * 4, st));
   if (n_jobs > 0 && total_mbs > 0) {
     if (sw) hipLaunchKernelGGL (lh264sw::coder_emit_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, job_chain, n_jobs, seg_doff, info, D);
-    else hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, job_chain, n_jobs, log2p, seg_doff, seg_cnt, seg_part, info, D);
+    else hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, job_chain, n_jobs, log2p, seg_doff, seg_cnt, seg_part, chain_map, info, D);
     HIPCHK (hipGetLastError());
   }
   W.info = info; W.D = D; W.Q = Q; W.pair_chunk0 = pair_chunk0; W.pair_bits = pair_bits; W.chunk_rec = chunk_rec; W.acc = acc;
@@ -659,6 +671,24 @@ long long lh264_debug_coder_seeds (uint32_t* out, long long cap) {
   return n;
 }
 #endif
+// tuning aid (not declared in lh264.h): decisions per partition of stream `chain` of the last wave-form coder call on the current device;
+// returns the number of partitions, -1 if there is nothing to read
+int lh264_debug_coder_parts (int chain, unsigned long long* out, int cap) {
+  int dev = 0; (void)hipGetDevice (&dev);
+  CoderWs& W = g_coder_ws[dev];
+  if (W.sw || !W.seg_part || !W.seg0 || !W.chain_first) return -1;
+  (void)hipDeviceSynchronize();
+  int32_t cf[2]; uint32_t sg[2];
+  if (hipMemcpy (cf, W.chain_first + chain, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy (&sg[0], W.seg0 + cf[0], 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy (&sg[1], W.seg0 + cf[1], 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const int P = 1 << W.log2p;
+  if (P > cap) return -1;
+  std::vector<uint32_t> rows ((size_t) (sg[1] - sg[0]) * (size_t) (P + 1));
+  if (hipMemcpy (rows.data(), W.seg_part + (size_t)sg[0] * (size_t) (P + 1), rows.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  for (int p = 0; p < P; p++) out[p] = 0;
+  for (size_t g = 0; g < sg[1] - sg[0]; g++) for (int p = 0; p < P; p++) out[p] += rows[g * (P + 1) + p + 1] - rows[g * (P + 1) + p];
+  return P;
+}
 #ifdef LH264_STAMP
 // diagnostic builds only (not declared in lh264.h)
 void lh264_debug_read_stamps (unsigned long long* out16, int reset) { lh264::read_stamps (out16, reset != 0); }

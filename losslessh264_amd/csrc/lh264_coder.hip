@@ -324,6 +324,9 @@ __device__ __forceinline__ uint32_t cell_part (uint32_t key, int log2p) {
 // form; CODER_RAW_KEY: the shared TEST_PROB), 32..35 the place in the cell, 36 the bit, 37..63 the entry of the stream's tag lists the
 // decision becomes (a stream's lists hold fewer than 2^27 entries per call; coder_scan_kernel checks it)
 #define CODER_QPOS_BITS 27
+// the cells are hashed into this many buckets; a stream's partitions are made of its buckets (coder_balance_kernel)
+#define CODER_LOG2_BUCKETS LH264_CODER_MAX_LOG2P
+#define CODER_BUCKETS (1 << CODER_LOG2_BUCKETS)
 
 // order LDS traffic between the lanes of one wave: the DS instructions of a wave execute in issue order, so all that is needed is to
 // keep the COMPILER from moving memory operations across this point
@@ -481,8 +484,9 @@ __device__ __forceinline__ uint32_t sym_key (uint32_t prior, int kind) {
   }
 }
 __global__ void __launch_bounds__ (256)
-coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ seg_job, int n_jobs, int log2p,
-                    uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_part) {
+coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ seg_job, int n_jobs,
+                    uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_bkt) {
+  const int log2p = CODER_LOG2_BUCKETS;            // (the cells are counted per bucket; coder_balance_kernel makes partitions of the buckets)
   __shared__ CountLds Lg[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   LDS CountLds& L = * (LDS CountLds*) (uintptr_t) (uint32_t) (uintptr_t)&Lg[wave];
@@ -498,7 +502,6 @@ coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* _
   // (the partitions: one counter each for the wave - the lanes of a step spread over them)
   auto padd = [&] (uint32_t part, uint32_t n) { __hip_atomic_fetch_add (&L.pcnt[part], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   unsigned long long touch = 0;
-  const int P = 1 << log2p;
   const uint32_t praw = cell_part (CODER_RAW_KEY, log2p);
   auto account = [&] (const SymCount c) {
     if (c.s0 >= 0) add (c.s0, (uint32_t)c.n0);
@@ -576,11 +579,79 @@ coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* _
       for (int i = 0; i < 32; i++) { const uint32_t v = L.col[t * 32 + ((i + lane) & 31)]; sum += (v & 0xffffu) + (v >> 16); }
     if (t < CNT_SLOTS) seg_cnt[(size_t)seg * LH264_CODER_CNT_STRIDE + t] = sum | (t < LH264_N_TAG_SLOTS ? (uint32_t) ((touch >> t) & 1ull) << 31 : 0u);
   }
-  // the partitions: running sum -> where each partition's run starts inside the segment's words
+  // decisions per bucket of cells
+  GLB uint32_t* sb = glb<uint32_t> (seg_bkt) + (size_t)seg * CODER_BUCKETS;
+  for (int p0 = 0; p0 < CODER_BUCKETS; p0 += 64) sb[p0 + lane] = L.pcnt[p0 + lane];
+}
+
+// ---- kernel 1b: the partitions of a stream = its buckets of cells dealt out evenly ------------------------------------------------------
+// One DynProb belongs to one wave of the resolve kernel, and the kernel takes as long as its busiest wave.  The decisions of a stream are
+// far from even over the cells (TEST_PROB alone - every raw bit - had 5.5 % of a 1080p stream's decisions, single cells 2-3 %): with the cells
+// hashed straight into 16 partitions the largest one held 1.7-1.9 times the mean.  So the cells are hashed into CODER_BUCKETS = 128
+// buckets, the stream's decisions per bucket are added up over its segments, and the buckets are dealt to the P partitions largest first,
+// each to the partition with the least so far.  chain_map[stream][bucket] = partition.  One wave per stream.
+__global__ void __launch_bounds__ (64)
+coder_balance_kernel (const uint32_t* __restrict__ seg0, const int32_t* __restrict__ chain_first, const uint32_t* __restrict__ seg_bkt, int n_chains, int log2p,
+                      uint8_t* __restrict__ chain_map) {
+  static_assert (CODER_BUCKETS == 128, "two buckets per lane");
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (c >= n_chains) return;
+  GLB uint8_t* map = glb<uint8_t> (chain_map) + (size_t)c * CODER_BUCKETS;
+  const int P = 1 << log2p;
+  if (P >= CODER_BUCKETS) { map[lane] = (uint8_t)lane; map[lane + 64] = (uint8_t) (lane + 64); return; }
+  const size_t m0 = seg0[chain_first[c]], m1 = seg0[chain_first[c + 1]];
+  unsigned long long t0 = 0, t1 = 0;
+  const GLB uint32_t* sb = glb<const uint32_t> (seg_bkt) + lane;
+  for (size_t g0 = m0; g0 < m1; g0 += 8) {                 // (eight segments' rows under way at a time)
+    uint32_t a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { a[k] = g0 + k < m1 ? sb[(g0 + k) * CODER_BUCKETS] : 0u; b[k] = g0 + k < m1 ? sb[(g0 + k) * CODER_BUCKETS + 64] : 0u; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { t0 += a[k]; t1 += b[k]; }
+  }
+  // largest remaining bucket -> least loaded partition; ties by index (the result depends on the counts alone)
+  unsigned long long load = 0;                             // lanes < P: decisions dealt to partition `lane`
+  bool done0 = false, done1 = false;
+  for (int it = 0; it < CODER_BUCKETS; it++) {
+    // (count, 127 - bucket) as one 64-bit key: the maximum is the largest count, the lowest bucket among equals
+    unsigned long long k0 = done0 ? 0ull : (t0 << 8 | (unsigned long long) (255 - lane)), k1 = done1 ? 0ull : (t1 << 8 | (unsigned long long) (255 - (lane + 64)));
+    unsigned long long best = k0 > k1 ? k0 : k1;
+    for (int m = 1; m < 64; m <<= 1) { const unsigned long long o = (unsigned long long)__shfl_xor ((long long)best, m); best = o > best ? o : best; }
+    const int bucket = 255 - (int) (best & 0xffull);
+    const unsigned long long cnt = best >> 8;
+    unsigned long long lk = lane < P ? (load << 8 | (unsigned long long)lane) : ~0ull;
+    for (int m = 1; m < 64; m <<= 1) { const unsigned long long o = (unsigned long long)__shfl_xor ((long long)lk, m); lk = o < lk ? o : lk; }
+    const int part = (int) (lk & 0xffull);
+    if (lane == part) load += cnt;
+    if (bucket == lane) { done0 = true; map[lane] = (uint8_t)part; }
+    if (bucket == lane + 64) { done1 = true; map[lane + 64] = (uint8_t)part; }
+  }
+}
+
+// ---- kernel 1c: where each partition's run starts inside a segment's decision words ------------------------------------------------------
+// seg_part[segment][p] = decisions of the segment in partitions < p ([P]: all).  One wave per segment.
+__global__ void __launch_bounds__ (256)
+coder_partoff_kernel (const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ seg_job, const uint32_t* __restrict__ job_chain, int n_jobs, int log2p,
+                      const uint32_t* __restrict__ seg_bkt, const uint8_t* __restrict__ chain_map, uint32_t* __restrict__ seg_part) {
+  __shared__ uint32_t pc[4][LH264_CODER_MAX_PARTS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
+  if (seg >= seg0[n_jobs]) return;
+  LDS uint32_t* pcnt = (LDS uint32_t*) (uintptr_t) (uint32_t) (uintptr_t)&pc[wave][0];
+  const int P = 1 << log2p;
+  for (int i = lane; i < P; i += 64) pcnt[i] = 0;
+  wsync();
+  const GLB uint8_t* map = glb<const uint8_t> (chain_map) + (size_t)job_chain[seg_job[seg]] * CODER_BUCKETS;
+  const GLB uint32_t* sb = glb<const uint32_t> (seg_bkt) + (size_t)seg * CODER_BUCKETS;
+  for (int b = lane; b < CODER_BUCKETS; b += 64) {
+    const uint32_t v = sb[b];
+    if (v) __hip_atomic_fetch_add (pcnt + map[b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  wsync();
   GLB uint32_t* sp = glb<uint32_t> (seg_part) + (size_t)seg * (size_t) (P + 1);
   uint32_t carry = 0;
   for (int p0 = 0; p0 < P; p0 += 64) {
-    const uint32_t v = p0 + lane < P ? L.pcnt[p0 + lane] : 0u;
+    const uint32_t v = p0 + lane < P ? pcnt[p0 + lane] : 0u;
     const uint32_t incl = (uint32_t)wave_scan_add ((int)v);
     if (p0 + lane < P) sp[p0 + lane + 1] = carry + incl;
     carry += (uint32_t)__builtin_amdgcn_readlane ((int)incl, 63);
@@ -687,11 +758,12 @@ struct EmitLds {
   uint32_t starts[EMIT_BATCH * 46 / 32 + 2];      // bit d: a symbol's decisions start at decision d of the batch
   uint32_t tcur[LH264_N_TAG_SLOTS];  // next entry of each tag's list (within the stream's lists)
   uint32_t pcur[LH264_CODER_MAX_PARTS];   // next word of each partition's run (within the segment's words)
+  uint32_t map[CODER_BUCKETS / 4];        // bucket of cells -> partition (a byte each)
 };
 __global__ void __launch_bounds__ (256)
 coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ seg_job, const uint32_t* __restrict__ job_chain,
                    int n_jobs, int log2p, const uint32_t* __restrict__ seg_doff, const uint32_t* __restrict__ seg_cnt, const uint32_t* __restrict__ seg_part,
-                   const uint32_t* __restrict__ chain_info, uint64_t* __restrict__ D) {
+                   const uint8_t* __restrict__ chain_map, const uint32_t* __restrict__ chain_info, uint64_t* __restrict__ D) {
   __shared__ EmitLds Lg[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   LDS EmitLds& L = * (LDS EmitLds*) (uintptr_t) (uint32_t) (uintptr_t)&Lg[wave];
@@ -703,6 +775,7 @@ coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __
   GLB uint64_t* Dseg = glb<uint64_t> (D) + ((unsigned long long)I[LH264_CODER_INFO_DBASE] | (unsigned long long)I[LH264_CODER_INFO_DBASE + 1] << 32) + seg_doff[seg];
   if (lane < LH264_N_TAG_SLOTS) L.tcur[lane] = I[LH264_CODER_INFO_TAGBASE + lane] + seg_cnt[(size_t)seg * LH264_CODER_CNT_STRIDE + lane];
   for (int i = lane; i < (1 << log2p); i += 64) L.pcur[i] = seg_part[(size_t)seg * (size_t) ((1 << log2p) + 1) + i];
+  if (lane < CODER_BUCKETS / 4) L.map[lane] = ((const uint32_t*)chain_map)[(size_t)job_chain[S.job] * (CODER_BUCKETS / 4) + lane];
   wsync();
   for (uint32_t b0 = 0; b0 < S.total; b0 += EMIT_BATCH) {
     // the batch: symbols b0 .. b0 + 255 (four per lane, their loads under way together); those with decisions are kept, in coding
@@ -742,7 +815,7 @@ coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __
       const uint64_t sym = L.bsym[lo];
       const uint32_t shi = (uint32_t) (sym >> 32);
       const Decision dc = decision_at ((uint32_t)sym, (int) (int16_t) (shi & 0xffffu), (int) ((shi >> 16) & 0xffu), (int) (shi >> 24), (int) (d - (uint32_t)L.bS[lo]));
-      const uint32_t part = cell_part (dc.key, log2p);
+      const uint32_t part = ((const LDS uint8_t*)L.map)[cell_part (dc.key, CODER_LOG2_BUCKETS)];
       const unsigned long long vm = __ballot (valid);
       uint32_t tlo, thi, plo, phi;
       wave_match<6> ((uint32_t)dc.tag, vm, tlo, thi);

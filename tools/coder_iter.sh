@@ -6,3 +6,4 @@ timeout -k 10 900 python3 -m pytest tests/test_coder_gpu.py tests/test_sweep.py 
 tail -2 gpurun_out/$1_pytest.log
 bash tools/coder_path_trace.sh $1_c3 "" syn1080p_IP_8f.264 256 8 | grep -v "^W2026" | head -14 &&
 bash tools/coder_path_trace.sh $1_c2 "" syn720p_allI_4slices_8f.264 1024 4 | grep -v "^W2026" | head -14
+python3 $R/tools/coder_parts.py syn1080p_IP_8f.264 256 8 | tail -2
