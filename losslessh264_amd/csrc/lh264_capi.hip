@@ -34,7 +34,7 @@ __global__ void coder_bases_kernel (uint32_t* chain_info, int n_chains, unsigned
 __global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t* seg0, const uint32_t* seg_job, const uint32_t* job_chain, int n_jobs, int log2p,
                                    const uint32_t* seg_doff, const uint32_t* seg_cnt, const uint32_t* seg_part, const uint8_t* chain_map, const uint32_t* chain_info, uint64_t* D);
 __global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint32_t* seg0, const int32_t* chain_first,
-                                      const uint32_t* seg_doff, const uint32_t* seg_part, const uint64_t* D, uint16_t* Q, int n_chains, int log2p);
+                                      const uint32_t* seg_doff, const uint32_t* seg_part, const uint64_t* D, uint16_t* Q, int n_chains, int log2p, uint32_t* progress, int window);
 __global__ void coder_chunkmap_kernel (const uint32_t* chain_info, int n_pairs, uint32_t* pair_chunk0, uint32_t* pair_coarse0);
 __global__ void coder_range_seed_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_coarse0, int n_pairs, uint32_t* cand);
 __global__ void coder_range_walk1_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs, int groups,
@@ -278,6 +278,7 @@ struct CoderWs {
   uint32_t* pair_coarse0 = nullptr; uint32_t* seed = nullptr; uint32_t* coarse_bits = nullptr; size_t coarse_bound = 0; int n_pairs_last = 0;
   uint32_t* cand = nullptr; uint8_t* cand_end = nullptr;
   const uint32_t* seg0 = nullptr; const uint32_t* seg_doff = nullptr; const uint32_t* seg_part = nullptr; const int32_t* chain_first = nullptr; int log2p = 3; bool sw = false;
+  uint32_t* progress = nullptr; int window = 0;    // the resolve kernel's waves of a stream keep within `window` segments of one another
 };
 CoderWs g_coder_ws[16];
 int grow (void** p, size_t* cap, size_t need) {
@@ -322,7 +323,7 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
                o_totals = o_info + up256 ((size_t)n_chains * LH264_CODER_INFO_WORDS * 4), o_doff = o_totals + 256,
                o_sjob = o_doff + up256 (seg_bound * 4 + 4), o_cnt = o_sjob + up256 (seg_bound * 4 + 4), o_part = o_cnt + up256 (seg_bound * LH264_CODER_CNT_STRIDE * 4 + 4),
                o_bkt = o_part + up256 (sw ? 4 : seg_bound * pstride * 4 + 4), o_map = o_bkt + up256 (sw ? 4 : seg_bound * LH264_CODER_MAX_PARTS * 4),
-               small_need = o_map + up256 ((size_t)n_chains * LH264_CODER_MAX_PARTS);
+               o_prog = o_map + up256 ((size_t)n_chains * LH264_CODER_MAX_PARTS), small_need = o_prog + up256 ((size_t)n_chains * LH264_CODER_MAX_PARTS * 4);
   if (int rc = grow (&W.small, &W.small_cap, small_need)) return rc;
   uint8_t* sm = (uint8_t*)W.small;
   uint32_t* seg0 = (uint32_t*) (sm + o_seg0); uint32_t* job_chain = (uint32_t*) (sm + o_jobchain); uint32_t* info = (uint32_t*) (sm + o_info);
@@ -385,6 +386,8 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   W.pair_coarse0 = (uint32_t*) (bg + o_pco0); W.seed = (uint32_t*) (bg + o_seed); W.coarse_bits = (uint32_t*) (bg + o_cbits); W.coarse_bound = coarse_bound; W.n_pairs_last = n_pairs;
   W.cand = (uint32_t*) (bg + o_cand); W.cand_end = (uint8_t*) (bg + o_cend);
   W.seg0 = seg0; W.seg_doff = seg_doff; W.seg_part = seg_part; W.chain_first = chain_first_dev;
+  W.progress = (uint32_t*) (sm + o_prog); W.window = 3;
+  if (const char* e = getenv ("LH264_CODER_WINDOW")) W.window = atoi (e);      // (experiments; 0: the waves run free)
   HIPCHK (hipMemsetAsync (acc, 0, n_acc * 4, st));
   if (n_jobs > 0 && total_mbs > 0) {
     if (sw) hipLaunchKernelGGL (lh264sw::coder_emit_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, job_chain, n_jobs, seg_doff, info, D);
@@ -405,9 +408,10 @@ static int code_finish (CoderWs& W, const lh264_code_stream_t* streams_dev, int 
   const size_t chunk_bound = W.chunk_bound; const int n_pairs = W.n_pairs;
   W.ready_chains = -1;
   if (W.enter (st)) return fail (LH264_E_HIP, "hipStreamWaitEvent (coder work memory)");
+  if (!W.sw && W.progress) HIPCHK (hipMemsetAsync (W.progress, 0, ((size_t)n_chains << W.log2p) * 4, st));
   if (W.sw) hipLaunchKernelGGL (lh264sw::coder_resolve_kernel, dim3 (n_chains), dim3 (LH264_CODER_RESOLVE_THREADS), 0, st, streams_dev, info, D, Q, n_chains);
-  else hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 ((unsigned) ((((size_t)n_chains << W.log2p) + 3) / 4)), dim3 (256), 0, st, streams_dev, info, W.seg0, W.chain_first,
-                           W.seg_doff, W.seg_part, D, Q, n_chains, W.log2p);
+  else hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 ((unsigned) ((((size_t)n_chains + 7) / 8) * 8 * (((size_t)1 << W.log2p) >= 4 ? ((size_t)1 << W.log2p) / 4 : 1))), dim3 (256), 0, st, streams_dev, info, W.seg0, W.chain_first,
+                           W.seg_doff, W.seg_part, D, Q, n_chains, W.log2p, W.progress, W.window);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_status_kernel, dim3 ((n_chains + 255) / 256), dim3 (256), 0, st, streams_dev, info, n_chains);
   HIPCHK (hipGetLastError());

@@ -848,6 +848,11 @@ coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __
 // and the halving is done by the next reader.  An entry of the wave's LDS cache (and of the spill table in HBM) is 64 bits: counters in
 // bits 0..19, the DynProb's key (cell key << 4 | place, 36 bits) in bits 20..55, bit 63 set.  All zero = free.
 #define R2_WAVES 4
+#define R2_SYNC_EVERY 32u        // rounds between two looks at the other waves of the stream
+#define R2_SYNC_LOOKS 64         // at most this many looks (with a sleep between them) before going on regardless
+#ifndef R2_DMA_MOD
+#define R2_DMA_MOD ""          // cache policy of the decision word reads (LDS-DMA)
+#endif
 #ifndef R2_LOG2_BUCKETS
 #define R2_LOG2_BUCKETS 8
 #endif
@@ -1028,14 +1033,25 @@ struct RoundGen {
 __global__ void __launch_bounds__ (R2_WAVES * 64)
 coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t* __restrict__ chain_info, const uint32_t* __restrict__ seg0,
                       const int32_t* __restrict__ chain_first, const uint32_t* __restrict__ seg_doff, const uint32_t* __restrict__ seg_part,
-                      const uint64_t* __restrict__ D, uint16_t* __restrict__ Q, int n_chains, int log2p) {
+                      const uint64_t* __restrict__ D, uint16_t* __restrict__ Q, int n_chains, int log2p, uint32_t* __restrict__ progress, int window) {
   __shared__ ResolveLds Sg[R2_WAVES];
   const int lane = threadIdx.x & 63, wave = uniform ((int) (threadIdx.x >> 6));
   LDS ResolveLds& S = * (LDS ResolveLds*) (uintptr_t) (uint32_t) (uintptr_t)&Sg[wave];
-  const uint32_t wid = blockIdx.x * R2_WAVES + (uint32_t)wave;      // (stream, partition)
+  // (stream, partition) of this wave.  Workgroups go to the XCDs in turn (blockIdx.x mod 8), and every XCD has its own L2: the waves of
+  // a stream all write the stream's tag lists, 2-byte entries that only become whole sectors when the entries of ALL partitions have
+  // arrived - so a stream's workgroups are given block indices of one residue mod 8 and meet in one L2
+#ifndef R2_PLAIN_MAP
+  const uint32_t wgs = (1u << log2p) >= (uint32_t)R2_WAVES ? (1u << log2p) / R2_WAVES : 1u;      // workgroups per stream
+  const uint32_t xj = blockIdx.x >> 3;
+  const int chain = (int) ((xj / wgs) * 8u + (blockIdx.x & 7u));
+  const uint32_t part = (xj % wgs) * R2_WAVES + (uint32_t)wave;
+  if (chain >= n_chains || part >= (1u << log2p)) return;
+#else
+  const uint32_t wid = blockIdx.x * R2_WAVES + (uint32_t)wave;
   const int chain = (int) (wid >> log2p);
   const uint32_t part = wid & ((1u << log2p) - 1u);
   if (chain >= n_chains) return;
+#endif
   uint32_t* I = chain_info + (size_t)chain * LH264_CODER_INFO_WORDS;
   // the partition's share of the stream's spill table (hash_cap cells of 64 bytes = 8 entries each)
   const uint32_t hc = streams[chain].hash_cap;
@@ -1065,7 +1081,7 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
     // dword, saved and restored inside the statement)
     const uint32_t dst = (uint32_t)uniform ((int) (my_ring + slot * 512u));
     uint32_t keep;
-    asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+    asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" R2_DMA_MOD "\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %2, off" R2_DMA_MOD "\n\ts_mov_b32 m0, %0"
                   : "=&s"(keep) : "v"(src), "v"(src + 1), "s"(dst), "s"(dst + 256u) : "memory");
   };
   // rounds it (resolved in this iteration), it + 1 (looked up; a spilled answer is taken in this iteration), it + 2 (looked up in this
@@ -1087,9 +1103,24 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
   rs_lookup (S, T, tmask, (uint32_t)w1, (uint32_t) (w1 >> 32), (uint32_t)lane < n1, false, e1);
   uint32_t nres = (uint32_t)__popcll (__ballot (e0.inserted)) + (uint32_t)__popcll (__ballot (e1.inserted));
   bool pend_ok = false; uint32_t pend_q = 0, pend_v = 0;
+  // The waves of a stream keep near one another (a hint, never waited for beyond a bounded number of looks): a sector of a tag list is
+  // complete when the entries of ALL partitions have been written, and only sectors that complete while they are still in the L2 leave
+  // it whole - waves that drift apart by more than the L2 holds write every 2-byte entry to HBM as a partial sector of its own.
+  // progress[stream][partition] = the segment the wave has reached (0xffffffff: done).
+  GLB uint32_t* prog = (progress && window > 0 && (1 << log2p) <= 64) ? glb<uint32_t> (progress) + ((size_t)chain << log2p) : (GLB uint32_t*)0;
   RS_STAMP_DECL
   for (uint32_t it = 0; n0 != 0u; it++) {
     const bool v_cur = (uint32_t)lane < n0;
+    if (prog && (it & (R2_SYNC_EVERY - 1u)) == 0u) {
+      if (lane == 0) __hip_atomic_store (prog + part, G.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int look = 0; look < R2_SYNC_LOOKS; look++) {
+        uint32_t v = lane < (1 << log2p) ? __hip_atomic_load (prog + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        for (int m = 1; m < 64; m <<= 1) v = min (v, (uint32_t)__shfl_xor ((int)v, m));
+        if (G.g <= v + (uint32_t)window) break;
+        __builtin_amdgcn_s_sleep (64);
+      }
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (pend_ok) Qc[pend_q] = (uint16_t)pend_v;          // the list entry of the round resolved in the last iteration
     pend_ok = false;
     const uint32_t w_hi = (uint32_t) (w0 >> 32);
@@ -1195,6 +1226,7 @@ coder_resolve_kernel (const lh264_code_stream_t* __restrict__ streams, uint32_t*
 #endif
   }
   if (pend_ok) Qc[pend_q] = (uint16_t)pend_v;
+  if (prog && lane == 0) __hip_atomic_store (prog + part, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   RS_STAMP_FLUSH
 }
 #ifdef LH264_CODER_DEBUG
