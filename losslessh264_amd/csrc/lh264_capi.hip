@@ -35,13 +35,11 @@ __global__ void coder_emit_kernel (const lh264_code_job_t* jobs, const uint32_t*
                                    const uint32_t* seg_doff, const uint32_t* seg_cnt, const uint32_t* seg_part, const uint8_t* chain_map, const uint32_t* chain_info, uint64_t* D);
 __global__ void coder_resolve_kernel (const lh264_code_stream_t* streams, uint32_t* chain_info, const uint32_t* seg0, const int32_t* chain_first,
                                       const uint32_t* seg_doff, const uint32_t* seg_part, const uint64_t* D, uint16_t* Q, int n_chains, int log2p, uint32_t* progress, int window);
-__global__ void coder_chunkmap_kernel (const uint32_t* chain_info, int n_pairs, uint32_t* pair_chunk0, uint32_t* pair_coarse0);
-__global__ void coder_range_seed_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_coarse0, int n_pairs, uint32_t* cand);
-__global__ void coder_range_walk1_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs, int groups,
-                                          const uint32_t* cand, uint8_t* cand_end, uint32_t* chunk_rec, uint32_t* coarse_bits);
-__global__ void coder_range_cand_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs,
-                                         const uint32_t* cand, uint8_t* cand_end);
-__global__ void coder_range_link_kernel (const uint32_t* pair_coarse0, int n_pairs, const uint32_t* cand, const uint8_t* cand_end, uint32_t* seed, uint32_t* chain_info);
+__global__ void coder_chunkmap_kernel (const uint32_t* chain_info, int n_pairs, uint32_t* pair_chunk0, uint32_t* pair_coarse0, uint32_t* cand_list);
+__global__ void coder_range_seed_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_coarse0, int n_pairs, uint32_t* cand, uint32_t* cand_list, uint32_t long_list);
+__global__ void coder_range_first_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs, int groups,
+                                          unsigned n_cand, unsigned n_later, const uint32_t* cand, const uint32_t* cand_list, uint8_t* cand_end, uint8_t* cmap, uint32_t* chunk_rec, uint32_t* coarse_bits);
+__global__ void coder_range_link_kernel (const uint32_t* pair_coarse0, int n_pairs, const uint32_t* cand, const uint8_t* cand_end, const uint8_t* cmap, uint32_t* seed, uint32_t* chain_info);
 __global__ void coder_range_walk_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs,
                                          const uint32_t* cand, const uint32_t* seed, uint32_t* chunk_rec, uint32_t* coarse_bits);
 __global__ void coder_range_scan_kernel (const uint32_t* pair_coarse0, int n_pairs, uint32_t* coarse_bits, uint32_t* pair_bits);
@@ -276,7 +274,7 @@ struct CoderWs {
   uint32_t* info = nullptr; uint64_t* D = nullptr; uint16_t* Q = nullptr;
   uint32_t* pair_chunk0 = nullptr; uint32_t* pair_bits = nullptr; uint32_t* chunk_rec = nullptr; uint32_t* acc = nullptr;
   uint32_t* pair_coarse0 = nullptr; uint32_t* seed = nullptr; uint32_t* coarse_bits = nullptr; size_t coarse_bound = 0; int n_pairs_last = 0;
-  uint32_t* cand = nullptr; uint8_t* cand_end = nullptr;
+  uint32_t* cand = nullptr; uint8_t* cand_end = nullptr; uint8_t* cmap = nullptr; uint32_t* cand_list = nullptr;
   const uint32_t* seg0 = nullptr; const uint32_t* seg_doff = nullptr; const uint32_t* seg_part = nullptr; const int32_t* chain_first = nullptr; int log2p = 3; bool sw = false;
   uint32_t* progress = nullptr; int window = 0;    // the resolve kernel's waves of a stream keep within `window` segments of one another
 };
@@ -376,7 +374,7 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   const size_t coarse_bound = (size_t)n_q / LH264_CODER_CODE_COARSE + 2 * (size_t)n_pairs + 1;
   const size_t o_q = up256 ((size_t)n_words * 8 + 512), o_pc0 = o_q + up256 ((size_t)n_q * 2 + 256), o_pbits = o_pc0 + up256 ((size_t) (n_pairs + 1) * 4),
                o_crec = o_pbits + up256 ((size_t)n_pairs * 4), o_pco0 = o_crec + up256 (chunk_bound * 8), o_seed = o_pco0 + up256 ((size_t) (n_pairs + 1) * 4),
-               o_cand = o_seed + up256 (coarse_bound * 4), o_cend = o_cand + up256 (coarse_bound * 12), o_cbits = o_cend + up256 (coarse_bound * 8),
+               o_cand = o_seed + up256 (coarse_bound * 4), o_cend = o_cand + up256 (coarse_bound * 12), o_cmap = o_cend + up256 (coarse_bound * 8), o_clist = o_cmap + up256 (coarse_bound * 128), o_cbits = o_clist + up256 (coarse_bound * 32 + 4),
                o_acc = o_cbits + up256 (coarse_bound * 4 + 4);
   if (int rc = grow (&W.big, &W.big_cap, o_acc + n_acc * 4 + 256)) return rc;
   uint8_t* bg = (uint8_t*)W.big;
@@ -384,7 +382,7 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   uint32_t* pair_chunk0 = (uint32_t*) (bg + o_pc0); uint32_t* pair_bits = (uint32_t*) (bg + o_pbits);
   uint32_t* chunk_rec = (uint32_t*) (bg + o_crec); uint32_t* acc = (uint32_t*) (bg + o_acc);
   W.pair_coarse0 = (uint32_t*) (bg + o_pco0); W.seed = (uint32_t*) (bg + o_seed); W.coarse_bits = (uint32_t*) (bg + o_cbits); W.coarse_bound = coarse_bound; W.n_pairs_last = n_pairs;
-  W.cand = (uint32_t*) (bg + o_cand); W.cand_end = (uint8_t*) (bg + o_cend);
+  W.cand = (uint32_t*) (bg + o_cand); W.cand_end = (uint8_t*) (bg + o_cend); W.cmap = bg + o_cmap; W.cand_list = (uint32_t*) (bg + o_clist);
   W.seg0 = seg0; W.seg_doff = seg_doff; W.seg_part = seg_part; W.chain_first = chain_first_dev;
   W.progress = (uint32_t*) (sm + o_prog); W.window = 3;
   if (const char* e = getenv ("LH264_CODER_WINDOW")) W.window = atoi (e);      // (experiments; 0: the waves run free)
@@ -415,21 +413,23 @@ static int code_finish (CoderWs& W, const lh264_code_stream_t* streams_dev, int 
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_status_kernel, dim3 ((n_chains + 255) / 256), dim3 (256), 0, st, streams_dev, info, n_chains);
   HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_chunkmap_kernel, dim3 (1), dim3 (1024), 0, st, info, n_pairs, pair_chunk0, W.pair_coarse0);
+  hipLaunchKernelGGL (lh264::coder_chunkmap_kernel, dim3 (1), dim3 (1024), 0, st, info, n_pairs, pair_chunk0, W.pair_coarse0, W.cand_list);
   HIPCHK (hipGetLastError());
-  // the bool coders' range recurrence in coarse chunks: start states by lookback, the walk, the running sum of the bits
-  hipLaunchKernelGGL (lh264::coder_range_seed_kernel, dim3 ((unsigned) ((W.coarse_bound + 3) / 4)), dim3 (256), 0, st, info, Q, W.pair_coarse0, n_pairs, W.cand);
+  // the bool coders' range recurrence in coarse chunks: start states by lookback, the walk, the running sum of the bits.
+  // Lists up to long_list decisions are walked whole by one lane: with many moderate streams (the QCIF batch: 0.7 M decisions a stream)
+  // every list is one of thousands and candidates are wasted walks; with large streams (5 - 23 M decisions) the lists of 65 - 262 k
+  // decisions were the longest lanes of the launch (1080p batch 18.4 -> 14.5 ms, QCIF batch 1.2 -> 1.4 ms the other way)
+  const uint32_t long_list = n_chains > 0 && W.last_q / (unsigned long long)n_chains > 4000000ull ? (uint32_t)LH264_CODER_CODE_COARSE : 262144u;
+  hipLaunchKernelGGL (lh264::coder_range_seed_kernel, dim3 ((unsigned) ((W.coarse_bound + 3) / 4)), dim3 (256), 0, st, info, Q, W.pair_coarse0, n_pairs, W.cand, W.cand_list, long_list);
   HIPCHK (hipGetLastError());
   const int groups = (n_chains + 63) / 64;
-  hipLaunchKernelGGL (lh264::coder_range_walk1_kernel, dim3 ((unsigned)groups * 35), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs, groups,
-                      W.cand, W.cand_end, chunk_rec, W.coarse_bits);
-  HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_range_walk1_kernel, dim3 ((unsigned) ((W.coarse_bound + 63) / 64)), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs, 0,
-                      W.cand, W.cand_end, chunk_rec, W.coarse_bits);
-  HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_range_cand_kernel, dim3 ((unsigned) ((W.coarse_bound + 7) / 8)), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs, W.cand, W.cand_end);
-  HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_range_link_kernel, dim3 ((unsigned) ((n_pairs + 63) / 64)), dim3 (64), 0, st, W.pair_coarse0, n_pairs, W.cand, W.cand_end, W.seed, info);
+  {
+    const unsigned n_cand = (unsigned) ((W.coarse_bound + 7) / 8), n_later = (unsigned) ((W.coarse_bound + 63) / 64);
+    hipLaunchKernelGGL (lh264::coder_range_first_kernel, dim3 (n_cand + (unsigned)groups * 35 + n_later + (unsigned)W.coarse_bound), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0,
+                        n_pairs, groups, n_cand, n_later, W.cand, W.cand_list, W.cand_end, W.cmap, chunk_rec, W.coarse_bits);
+    HIPCHK (hipGetLastError());
+  }
+  hipLaunchKernelGGL (lh264::coder_range_link_kernel, dim3 ((unsigned) ((n_pairs + 63) / 64)), dim3 (64), 0, st, W.pair_coarse0, n_pairs, W.cand, W.cand_end, W.cmap, W.seed, info);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_range_walk_kernel, dim3 ((unsigned) ((W.coarse_bound + 63) / 64)), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs,
                       W.cand, W.seed, chunk_rec, W.coarse_bits);

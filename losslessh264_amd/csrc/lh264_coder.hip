@@ -1297,7 +1297,8 @@ __device__ __forceinline__ PairInfo pair_info (const uint32_t* chain_info, const
 
 // kernel 6: chunks per (stream, tag) pair and their running sum (one workgroup)
 __global__ void __launch_bounds__ (1024)
-coder_chunkmap_kernel (const uint32_t* __restrict__ chain_info, int n_pairs, uint32_t* __restrict__ pair_chunk0, uint32_t* __restrict__ pair_coarse0) {
+coder_chunkmap_kernel (const uint32_t* __restrict__ chain_info, int n_pairs, uint32_t* __restrict__ pair_chunk0, uint32_t* __restrict__ pair_coarse0, uint32_t* __restrict__ cand_list) {
+  if (threadIdx.x == 0) cand_list[0] = 0;                  // the walks from candidate start states the seed kernel will ask for
   __shared__ uint32_t wsum[16], wsum2[16];
   __shared__ uint32_t carry, carry2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1334,7 +1335,7 @@ coder_chunkmap_kernel (const uint32_t* __restrict__ chain_info, int n_pairs, uin
 //   coder_range_seed_kernel   one wave per coarse chunk: walks the CODE_LOOKBACK decisions in front of the chunk from ALL 128 states
 //                             (two per lane; the decision is wave-uniform) and notes the states that are left - the CANDIDATES for the
 //                             chunk's start state, at most 8; a chunk with more is left "unresolved".  Chunk 0 of a list starts at 255.
-//   coder_range_cand_kernel   one lane per (coarse chunk, candidate): the recurrence from the candidate over the chunk (and on through
+//   coder_range_first_kernel   one lane per (coarse chunk, candidate): the recurrence from the candidate over the chunk (and on through
 //                             unresolved chunks behind it) -> the state at the start of the next resolved chunk, IF the chunk starts there
 //   coder_range_link_kernel   one lane per pair: from 255 at the list's start, chunk after chunk: which candidate is the true start state,
 //                             what that makes the next chunk's
@@ -1359,20 +1360,20 @@ __device__ __forceinline__ uint32_t coarse_pair (const uint32_t* __restrict__ pa
 }
 
 #define CODE_LOOKBACK 1024u
-#define CODE_LONG_LIST 262144u
 #define CODE_CANDS 8
+#define CODE_MAPPED 0xffffffff00000000ull      // candidate words of a chunk with more than CODE_CANDS possible start states
 __global__ void __launch_bounds__ (256)
 coder_range_seed_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_coarse0, int n_pairs,
-                         uint32_t* __restrict__ cand) {
+                         uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_list, uint32_t long_list) {
   const uint32_t G = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (G >= pair_coarse0[n_pairs]) return;
   const uint32_t pair = (uint32_t)uniform ((int)coarse_pair (pair_coarse0, (uint32_t)n_pairs, G));
   const uint32_t c = G - pair_coarse0[pair];
   if (c == 0u) { if (lane < 2u) cand[2 * (size_t)G + lane] = lane == 0u ? 255u : 0u; return; }
   const PairInfo P = pair_info (chain_info, Q, pair);
-  // a list of moderate length is walked whole by the lane of its first chunk (10 ns a decision: 2.6 ms at most) - candidates cost
+  // a list of moderate length (the host's choice, lh264_capi.hip) is walked whole by the lane of its first chunk - candidates cost
   // several walks per chunk, which only pays where one lane would take longer than the rest of the coder
-  if (P.total <= CODE_LONG_LIST) { if (lane < 2u) cand[2 * (size_t)G + lane] = 0u; return; }
+  if (P.total <= long_list) { if (lane < 2u) cand[2 * (size_t)G + lane] = 0u; return; }
   const uint32_t b = c * CODE_COARSE;
   uint32_t r0 = 128u + lane, r1 = 192u + lane;
   for (uint32_t i0 = b - CODE_LOOKBACK; i0 < b; i0 += 64u) {
@@ -1397,11 +1398,20 @@ coder_range_seed_kernel (const uint32_t* __restrict__ chain_info, const uint16_t
     cs |= (unsigned long long)v << (8 * k);
     act0 = act0 && r0 != v; act1 = act1 && r1 != v;
   }
-  if (__ballot (act0 || act1)) cs = 0;                 // more than CODE_CANDS states left: unresolved
+  if (__ballot (act0 || act1)) cs = CODE_MAPPED;       // more than CODE_CANDS states left: the chunk's whole state map is worked out (coder_range_first_kernel)
 #ifdef LH264_RANGE_PROBE     // diagnostic build: how many distinct states are left, noted behind the candidates
   { uint32_t d = 0; for (uint32_t v = 128u; v < 256u; v++) d += __ballot (r0 == v || r1 == v) != 0ull; if (lane == 0u) cand[2 * (size_t)pair_coarse0[n_pairs] + G] = d; }
 #endif
   if (lane < 2u) cand[2 * (size_t)G + lane] = (uint32_t) (cs >> (32 * lane));
+  // several candidates: a walk from each - one dense list of (chunk, candidate) for coder_range_first_kernel (cand_list[0] = their number)
+  if (cs != CODE_MAPPED && (cs >> 8) != 0ull) {
+    int nc = 0;
+    for (int k = 0; k < CODE_CANDS; k++) nc += ((cs >> (8 * k)) & 0xffull) != 0ull;
+    uint32_t base = 0;
+    if (lane == 0u) base = atomicAdd (cand_list, (uint32_t)nc);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane ((int)base);
+    if (lane < (uint32_t)nc) cand_list[1u + base + lane] = G * CODE_CANDS + lane;
+  }
 }
 
 struct RangeWalk {
@@ -1464,50 +1474,91 @@ __device__ __forceinline__ uint32_t range_walk (const uint32_t* __restrict__ cha
       A.pos += code_step (A.range, i < n ? wj >> (16u * (j & 1u)) : CODE_STOP_ENTRY).shift;
     }
     if (NOTES) coarse_bits[G] = A.pos;                  // the bits this coarse chunk shifts out
-    if (G + 1u >= G_end || resolved[2 * (size_t) (G + 1u)] != 0u) break;   // the next chunk has a lane of its own (or there is none)
+    if (G + 1u >= G_end || resolved[2 * (size_t) (G + 1u)] != 0u || resolved[2 * (size_t) (G + 1u) + 1u] != 0u) break;   // the next chunk has a lane of its own (or there is none)
   }
   return A.range;
 }
-// one lane per coarse chunk with ONE candidate (every list's first chunk is one): that is its start state - the final walk at once.
-// Two launches: `groups` > 0 - the first chunks of all lists, a wave = one tag slot of 64 consecutive streams (lists of about the same
-// length in its lanes: a wave is as slow as its longest list); `groups` == 0 - the later chunks with one candidate, a lane per chunk.
+// The walks that need nothing but the candidates, in ONE launch (each of them is a few hundred waves walking serially - one after the
+// other they left the machine idle three times over; the launch's workgroups are dealt to the three in the order below, the longest first):
+//   blocks [0, 35 groups)         one lane per list: its first chunk starts at 255 - the final walk at once; a wave = one tag slot of 64
+//                                 consecutive streams (lists of about the same length in its lanes: a wave is as slow as its longest list).
+//                                 Few waves, each a long serial walk: they start first and the rest fills the machine around them
+//   blocks [.., + n_cand)         one lane per (coarse chunk with several candidates, candidate start state) of the seed kernel's list: where
+//                                 the walk ends
+//   the rest                      one lane per later coarse chunk with ONE candidate: that is its start state - the final walk at once
 __global__ void __launch_bounds__ (64)
-coder_range_walk1_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0,
-                          const uint32_t* __restrict__ pair_coarse0, int n_pairs, int groups, const uint32_t* __restrict__ cand, uint8_t* __restrict__ cand_end,
-                          uint32_t* __restrict__ chunk_rec, uint32_t* __restrict__ coarse_bits) {
+coder_range_first_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0,
+                          const uint32_t* __restrict__ pair_coarse0, int n_pairs, int groups, unsigned n_cand, unsigned n_later, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ cand_list,
+                          uint8_t* __restrict__ cand_end, uint8_t* __restrict__ cmap, uint32_t* __restrict__ chunk_rec, uint32_t* __restrict__ coarse_bits) {
+  const uint32_t n_first = (uint32_t)groups * 35u;
   uint32_t G;
-  if (groups > 0) {
+  if (blockIdx.x < n_first) {
     const uint32_t slot = blockIdx.x / (uint32_t)groups, chain = (blockIdx.x % (uint32_t)groups) * 64u + threadIdx.x;
     const uint32_t pair = chain * LH264_N_TAG_SLOTS + slot;
     if (pair >= (uint32_t)n_pairs) return;
     G = pair_coarse0[pair];
     if (pair_coarse0[pair + 1] == G) return;             // the tag has no list
-  } else {
-    G = blockIdx.x * 64u + threadIdx.x;
+  } else if (blockIdx.x < n_first + n_cand) {
+    const uint32_t idx = (blockIdx.x - n_first) * 64u + threadIdx.x;
+    if (idx >= cand_list[0]) return;
+    const uint32_t gk = cand_list[1u + idx], k = gk % CODE_CANDS;
+    G = gk / CODE_CANDS;
+    const uint32_t c0 = cand[2 * (size_t)G], c1 = cand[2 * (size_t)G + 1];
+    const uint32_t s0 = ((k < 4u ? c0 : c1) >> (8 * (k & 3))) & 0xffu;
+    cand_end[(size_t)G * CODE_CANDS + k] = (uint8_t)range_walk<false> (chain_info, Q, pair_chunk0, pair_coarse0, n_pairs, cand, G, s0, nullptr, nullptr);
+    return;
+  } else if (blockIdx.x < n_first + n_cand + n_later) {
+    G = (blockIdx.x - n_first - n_cand) * 64u + threadIdx.x;
     if (G >= pair_coarse0[n_pairs]) return;
-    if (G == pair_coarse0[coarse_pair (pair_coarse0, (uint32_t)n_pairs, G)]) return;      // a first chunk: the other launch's
+    if (G == pair_coarse0[coarse_pair (pair_coarse0, (uint32_t)n_pairs, G)]) return;      // a first chunk: walked above
+  } else {
+    // a wave per coarse chunk whose start state the lookback could not narrow down (a list that only rotates the states - a run of
+    // near-certain decisions): where EVERY start state ends, two states per lane, the decision wave-uniform.  Twelve instructions a
+    // decision for all 128 - a lane walking such a list on its own, chunk after chunk, was the longest wave of the launch (10.8 ms)
+    G = blockIdx.x - n_first - n_cand - n_later;
+    if (G >= pair_coarse0[n_pairs]) return;
+    if (cand[2 * (size_t)G] != 0u || cand[2 * (size_t)G + 1] != (uint32_t) (CODE_MAPPED >> 32)) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t pair = (uint32_t)uniform ((int)coarse_pair (pair_coarse0, (uint32_t)n_pairs, G));
+    const PairInfo P = pair_info (chain_info, Q, pair);
+    const uint32_t i0 = (G - pair_coarse0[pair]) * CODE_COARSE, i1 = min (i0 + CODE_COARSE, P.total);
+    uint32_t r0 = 128u + lane, r1 = 192u + lane;
+    uint32_t e_next = i0 + lane < P.n ? (uint32_t)P.list[i0 + lane] : CODE_STOP_ENTRY;
+    for (uint32_t b = i0; b < i1; b += 64u) {
+      const uint32_t e = e_next;
+      e_next = b + 64u + lane < P.n ? (uint32_t)P.list[b + 64u + lane] : CODE_STOP_ENTRY;
+      const int cnt = (int)min (64u, i1 - b);
+      if (cnt == 64) {
+#pragma unroll 8
+        for (int i = 0; i < 64; i++) {
+          const uint32_t ei = (uint32_t)__builtin_amdgcn_readlane ((int)e, i);
+          const uint32_t q = (ei >> 1) & 0x1ffu, k = 256u - (ei & 1u) - q;
+          const uint32_t a0 = r0 * q + k, a1 = r1 * q + k;
+          r0 = (a0 >> 8) << __builtin_clz (a0 << 16);
+          r1 = (a1 >> 8) << __builtin_clz (a1 << 16);
+        }
+      } else {
+        for (int i = 0; i < cnt; i++) {
+          const uint32_t ei = (uint32_t)__shfl ((int)e, i);
+          const uint32_t q = (ei >> 1) & 0x1ffu, k = 256u - (ei & 1u) - q;
+          const uint32_t a0 = r0 * q + k, a1 = r1 * q + k;
+          r0 = (a0 >> 8) << __builtin_clz (a0 << 16);
+          r1 = (a1 >> 8) << __builtin_clz (a1 << 16);
+        }
+      }
+    }
+    cmap[(size_t)G * 128u + lane] = (uint8_t)r0; cmap[(size_t)G * 128u + 64u + lane] = (uint8_t)r1;
+    return;
   }
   const uint32_t c0 = cand[2 * (size_t)G], c1 = cand[2 * (size_t)G + 1];
   if (c0 == 0u || (c0 >> 8) != 0u || c1 != 0u) return;
   cand_end[(size_t)G * CODE_CANDS] = (uint8_t)range_walk<true> (chain_info, Q, pair_chunk0, pair_coarse0, n_pairs, cand, G, c0, chunk_rec, coarse_bits);
 }
-// one lane per (coarse chunk with several candidates, candidate start state): where the walk ends
-__global__ void __launch_bounds__ (64)
-coder_range_cand_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0,
-                         const uint32_t* __restrict__ pair_coarse0, int n_pairs, const uint32_t* __restrict__ cand, uint8_t* __restrict__ cand_end) {
-  const uint32_t G = blockIdx.x * (64u / CODE_CANDS) + threadIdx.x / CODE_CANDS, k = threadIdx.x % CODE_CANDS;
-  if (G >= pair_coarse0[n_pairs]) return;
-  const uint32_t c0 = cand[2 * (size_t)G], c1 = cand[2 * (size_t)G + 1];
-  if ((c0 >> 8) == 0u && c1 == 0u) return;              // none (unresolved) or one (walked by coder_range_walk1_kernel)
-  const uint32_t s0 = ((k < 4u ? c0 : c1) >> (8 * (k & 3))) & 0xffu;
-  if (s0 == 0u) return;
-  cand_end[(size_t)G * CODE_CANDS + k] = (uint8_t)range_walk<false> (chain_info, Q, pair_chunk0, pair_coarse0, n_pairs, cand, G, s0, nullptr, nullptr);
-}
 // one lane per pair: the true start state of every coarse chunk with several candidates (seed; 0 for the others: walked already, or
 // walked by the lane of the chunk in front of them)
 __global__ void __launch_bounds__ (64)
 coder_range_link_kernel (const uint32_t* __restrict__ pair_coarse0, int n_pairs, const uint32_t* __restrict__ cand, const uint8_t* __restrict__ cand_end,
-                         uint32_t* __restrict__ seed, uint32_t* __restrict__ chain_info) {
+                         const uint8_t* __restrict__ cmap, uint32_t* __restrict__ seed, uint32_t* __restrict__ chain_info) {
   const uint32_t pair = blockIdx.x * 64u + threadIdx.x;
   if (pair >= (uint32_t)n_pairs) return;
   uint32_t s = 255u;
@@ -1515,6 +1566,7 @@ coder_range_link_kernel (const uint32_t* __restrict__ pair_coarse0, int n_pairs,
   for (uint32_t G = pair_coarse0[pair]; G < pair_coarse0[pair + 1]; G++) {
     const unsigned long long cs = (unsigned long long)cand[2 * (size_t)G] | (unsigned long long)cand[2 * (size_t)G + 1] << 32;
     if (cs == 0ull) { seed[G] = 0u; continue; }
+    if (cs == CODE_MAPPED) { seed[G] = s; s = cmap[(size_t)G * 128u + (s - 128u)]; continue; }      // every start state's end is known
     int k = -1;
     for (int q = CODE_CANDS - 1; q >= 0; q--) if (((cs >> (8 * q)) & 0xffull) == (unsigned long long)s) k = q;
     if (k < 0) { lost = true; k = 0; }                 // (cannot happen: the lookback starts from every state)
