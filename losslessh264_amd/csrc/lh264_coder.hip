@@ -1679,7 +1679,7 @@ coder_accum_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __r
 
 // kernel 9: carries, bytes, lengths.  vpx_write puts a byte out whenever 8 more bits have been shifted out beyond the first 24:
 // bytes = (bits - 24) / 8 + 1; byte k is byte position k of the sum.  vpx_stop_encode appends a zero byte behind a last byte 110xxxxx.
-// One WAVE per pair, 64 positions per step from the last to the first (round 2: one lane per pair, a position at a time - 30 ms for the
+// One WAVE per pair, 256 positions per step from the last to the first (round 2: one lane per pair, a position at a time - 30 ms for the
 // 1080p batch's megabyte tags).  A position's sum holds up to 32 bits, i.e. it reaches three positions up; two local steps bring
 // every position down to a digit of at most 258 - B[k] = the bytes of A[k .. k+3] that fall on k (< 1024), C[k] = B[k] mod 256 + B[k+1]
 // div 256 - and from there on a carry is one bit: a position generates one (C >= 256), passes one on (C == 255) or ends it.  The
@@ -1703,31 +1703,42 @@ coder_bytes_kernel (const lh264_code_stream_t* __restrict__ streams, const uint3
   const bool wide = (((uintptr_t)o) & 3u) == 0u;
   const uint32_t last = (bits >> 3) + 2u;                      // no addend lies behind this position (the sums behind it read zero)
   uint32_t cin = 0, final_byte = 0;
-  // lane i of a step holds position k0 + 63 - i: bit i of a lane mask is then the bit a carry moves UP from towards bit i + 1
-  for (uint32_t k0 = last & ~63u; ; k0 -= 64u) {
-    const uint32_t k = k0 + 63u - lane;
-    // (behind `last` the next pair's sums begin: read as zero)
-    const uint32_t a0 = k <= last ? A[k] : 0u, a1 = k + 1u <= last ? A[k + 1u] : 0u, a2 = k + 2u <= last ? A[k + 2u] : 0u,
-                   a3 = k + 3u <= last ? A[k + 3u] : 0u, a4 = k + 4u <= last ? A[k + 4u] : 0u;
-    const uint32_t B0 = (a0 & 255u) + ((a1 >> 8) & 255u) + ((a2 >> 16) & 255u) + (a3 >> 24);
-    const uint32_t B1 = (a1 & 255u) + ((a2 >> 8) & 255u) + ((a3 >> 16) & 255u) + (a4 >> 24);
-    const uint32_t C = (B0 & 255u) + (B1 >> 8);
-    const unsigned long long G = __ballot (C >= 256u), Pm = __ballot (C == 255u);
+  // A lane holds FOUR consecutive positions (one dword of output), lane i of a step the positions k0 + 4 (63 - i) .. + 3: bit i of a lane
+  // mask is then the bit a carry moves UP from towards bit i + 1.  Inside its four positions a lane works the carry out for both
+  // cases - none coming in, one coming in - and the wave's two additions pick: 256 positions per step (a position per lane and step
+  // took 10 ms for the 1080p batch's 850 KB tags: 13 k dependent steps of two ballots and three lane exchanges each).
+  for (uint32_t k0 = last & ~255u; ; k0 -= 256u) {
+    const uint32_t p0 = k0 + 4u * (63u - lane);
+    // (loads of a clamped index, the value masked afterwards: a load under a branch is waited for before the next one is issued;
+    // behind `last` the next pair's sums begin - read as zero)
+    uint32_t a[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) a[q] = A[min (p0 + (uint32_t)q, last)];
+#pragma unroll
+    for (int q = 0; q < 8; q++) a[q] = p0 + (uint32_t)q <= last ? a[q] : 0u;
+    uint32_t B[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) B[q] = (a[q] & 255u) + ((a[q + 1] >> 8) & 255u) + ((a[q + 2] >> 16) & 255u) + (a[q + 3] >> 24);
+    uint32_t c0 = 0, c1 = 1, y0 = 0, y1 = 0;                     // the four bytes without / with a carry coming in, the carry going out
+#pragma unroll
+    for (int q = 3; q >= 0; q--) {
+      const uint32_t C = (B[q] & 255u) + (B[q + 1] >> 8);
+      const uint32_t t0 = C + c0, t1 = C + c1;
+      y0 |= (t0 & 255u) << (8 * q); c0 = t0 >> 8;
+      y1 |= (t1 & 255u) << (8 * q); c1 = t1 >> 8;
+    }
+    const unsigned long long G = __ballot (c0 != 0u), Pm = __ballot (c0 == 0u && c1 != 0u);
     const unsigned long long X = G | Pm, s1 = X + G, s2 = s1 + cin;
     const uint32_t cout = (s1 < X || s2 < s1) ? 1u : 0u;
-    const unsigned long long carries = s2 ^ Pm;                // bit i: the carry INTO position k0 + 63 - i
-    const uint32_t byte = (C + (uint32_t) ((carries >> lane) & 1ull)) & 255u;
+    const unsigned long long carries = s2 ^ Pm;                // bit i: the carry INTO lane i's positions
+    const uint32_t y = ((carries >> lane) & 1ull) ? y1 : y0;
     cin = cout;
-    if (nbytes > 0u && k == nbytes - 1u) final_byte = byte;
-    // four positions to a dword: lane i (i % 4 == 0) holds position k, lanes i + 1 .. i + 3 positions k - 1 .. k - 3
-    const uint32_t b1 = (uint32_t)__shfl_down ((int)byte, 1), b2 = (uint32_t)__shfl_down ((int)byte, 2), b3 = (uint32_t)__shfl_down ((int)byte, 3);
-    if ((lane & 3u) == 0u && k - 3u < nbytes) {
-      if (wide && k < nbytes && k < cap) * (GLB uint32_t*) (o + (k - 3u)) = b3 | b2 << 8 | b1 << 16 | byte << 24;
+    if (nbytes > 0u && nbytes - 1u - p0 < 4u) final_byte = (y >> (8u * (nbytes - 1u - p0))) & 255u;
+    if (p0 < nbytes) {
+      if (wide && p0 + 3u < nbytes && p0 + 3u < cap) * (GLB uint32_t*) (o + p0) = y;
       else {
-        if (k - 3u < nbytes && k - 3u < cap) o[k - 3u] = (uint8_t)b3;
-        if (k - 2u < nbytes && k - 2u < cap) o[k - 2u] = (uint8_t)b2;
-        if (k - 1u < nbytes && k - 1u < cap) o[k - 1u] = (uint8_t)b1;
-        if (k < nbytes && k < cap) o[k] = (uint8_t)byte;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (p0 + (uint32_t)q < nbytes && p0 + (uint32_t)q < cap) o[p0 + (uint32_t)q] = (uint8_t) (y >> (8 * q));
       }
     }
     if (k0 == 0u) break;
