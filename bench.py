@@ -583,12 +583,13 @@ def main():
                                                  "coefficient symbol) + a9/a10 (binarisation, adaptive probabilities, bool coders): the whole compress direction "
                                                  "on the device, records in HBM -> tagged byte streams in HBM; the host CAVLC/CABAC parse is not in this step",
                        "parallelism": "reconstruct: one workgroup per stream, one wave per MB row; context indices: a wave per macroblock (compact symbol pool); "
-                                      "coder, chosen per call: many small streams - a thread per symbol (binarise), one workgroup per stream (adaptive "
-                                      "probabilities); few large streams - a lane per decision into per-partition runs, one wave per (stream, partition); then for "
-                                      "both the bool coders: range walk in coarse chunks from checked candidate start states, one lane per 256 decisions (sums), "
-                                      "one wave per (stream, tag) (carries); the reconstruct kernel runs on a second HIP stream beside the context-index and coder "
-                                      "kernels; streams sharded across GPUs",
-                       "coder_form": ("stream per workgroup" if n_local >= 384 and sess.n_mbs_total / max(1, n_local) <= 12288 else "wave per (stream, partition)"),
+                                      "coder, two forms (config.coder_form): a lane per decision into per-partition runs (a stream's cells dealt evenly to 8 or 16 "
+                                      "partitions), one wave per (stream, partition) for the adaptive probabilities - or, a few hundred small streams, a thread "
+                                      "per symbol and one workgroup per stream; the bool coders: range walk in coarse chunks from checked candidate "
+                                      "start states, one lane per 256 decisions (sums), one wave per (stream, tag) (carries); the reconstruct kernel runs on a "
+                                      "second HIP stream beside the context-index and coder kernels; streams sharded across GPUs",
+                       "coder_form": ("stream per workgroup" if (os.environ.get("LH264_CODER_PATH") == "sw" or (os.environ.get("LH264_CODER_PATH") != "wave" and 384 <= n_local < 1024
+                                                                         and sess.n_mbs_total / max(1, n_local) <= 12288)) else "wave per (stream, partition)"),
                        "stage_ms_note": "stage times are from steps run on one stream; in the timed steps the stages overlap, ms_per_step is less than their sum",
                        "pipeline": ("two batches in flight: the context-index kernels (row a8) of the next batch run on a third HIP stream beside the second half of "
                                     "this batch's coder; every step launches every kernel of rows a1-a10 once" if pipeline else "none: every batch on its own"),

@@ -299,17 +299,20 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   if (W.enter (st)) return fail (LH264_E_HIP, "hipStreamWaitEvent (coder work memory)");
   if (!W.totals_host) HIPCHK (hipHostMalloc ((void**)&W.totals_host, 2 * sizeof (unsigned long long), hipHostMallocDefault));
   // Two forms of the first stages (binarisation, adaptive probabilities), chosen per call:
-  //   stream per workgroup (lh264_coder_sw.hip): a stream's decisions in coding order, one workgroup of 8 waves resolves them - the
-  //     faster form when the batch has hundreds of streams of moderate size (one LDS cache per stream, 512 decisions per step)
-  //   wave per (stream, partition) (lh264_coder.hip): scales inside a stream - few, large streams
+  //   wave per (stream, partition) (lh264_coder.hip): scales inside a stream; with balanced partitions and the waves of a stream kept
+  //     together it is the faster one on nearly every batch measured (1,024 - 2,048 QCIF streams, the mixed batch, 1,024 CIF streams,
+  //     the 720p and 1080p batches: by 2 - 15 %)
+  //   stream per workgroup (lh264_coder_sw.hip): a stream's decisions in coding order, one workgroup of 8 waves resolves them - round
+  //     2's form; still 2 % ahead where a batch is a few hundred small streams of about the same size (512 QCIF streams: 26.6 against
+  //     27.2 ms a step beside the reconstruct kernel - it leaves that kernel more of the vector ALUs)
   // LH264_CODER_PATH=sw|wave overrides, for the tests (both forms must give the same bytes) and for experiments.
-  bool sw = n_chains >= 384 && total_mbs / n_chains <= 12288;
+  bool sw = n_chains >= 384 && n_chains < 1024 && total_mbs / n_chains <= 12288;
   if (const char* e = getenv ("LH264_CODER_PATH")) { if (!strcmp (e, "sw")) sw = true; else if (!strcmp (e, "wave")) sw = false; }
   W.sw = sw;
   // the partitions of a stream's DynProbs (each resolved by a wave of its own): as few as fill the machine with waves - a partition's
   // runs of decision words get shorter with their number, and a run costs its wave a look at the segment tables
   // (LH264_CODER_LOG2P overrides, for experiments)
-  int log2p = n_chains > 512 ? 3 : 4;       // (measured: 512 x 16 and 256 x 16 beat 512 x 8 and 256 x 32, 1024 x 8 is enough waves)
+  int log2p = n_chains >= 512 ? 3 : 4;      // (measured: 256 x 16 beats 256 x 32; 512 x 8 beats 512 x 16 - 4.9 against 6.6 ms; 1,024 x 8 and 2,048 x 8 beat x 4)
   while (log2p < LH264_CODER_MAX_LOG2P && ((long long)n_chains << log2p) < 2048) log2p++;
   if (const char* e = getenv ("LH264_CODER_LOG2P")) { const int v = atoi (e); if (v >= 0 && v <= LH264_CODER_MAX_LOG2P) log2p = v; }
   W.log2p = log2p;
