@@ -42,7 +42,8 @@ __global__ void coder_range_first_kernel (const uint32_t* chain_info, const uint
 __global__ void coder_range_link_kernel (const uint32_t* pair_coarse0, int n_pairs, const uint32_t* cand, const uint8_t* cand_end, const uint8_t* cmap, uint32_t* seed, uint32_t* chain_info);
 __global__ void coder_range_walk_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs,
                                          const uint32_t* cand, const uint32_t* seed, uint32_t* chunk_rec, uint32_t* coarse_bits);
-__global__ void coder_range_scan_kernel (const uint32_t* pair_coarse0, int n_pairs, uint32_t* coarse_bits, uint32_t* pair_bits);
+__global__ void coder_range_scan_kernel (const uint32_t* pair_coarse0, int n_pairs, uint32_t* coarse_bits, uint32_t* pair_bits, const uint32_t* chain_info,
+                                         const uint16_t* Q, uint32_t* acc);
 __global__ void coder_accum_kernel (const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_chunk0, const uint32_t* pair_coarse0, int n_pairs,
                                     const uint32_t* chunk_rec, const uint32_t* coarse_bits, const uint32_t* pair_bits, uint32_t* acc);
 __global__ void coder_bytes_kernel (const lh264_code_stream_t* streams, const uint32_t* chain_info, const uint16_t* Q, const uint32_t* pair_bits,
@@ -389,7 +390,6 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   W.seg0 = seg0; W.seg_doff = seg_doff; W.seg_part = seg_part; W.chain_first = chain_first_dev;
   W.progress = (uint32_t*) (sm + o_prog); W.window = 3;
   if (const char* e = getenv ("LH264_CODER_WINDOW")) W.window = atoi (e);      // (experiments; 0: the waves run free)
-  HIPCHK (hipMemsetAsync (acc, 0, n_acc * 4, st));
   if (n_jobs > 0 && total_mbs > 0) {
     if (sw) hipLaunchKernelGGL (lh264sw::coder_emit_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, job_chain, n_jobs, seg_doff, info, D);
     else hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, job_chain, n_jobs, log2p, seg_doff, seg_cnt, seg_part, chain_map, info, D);
@@ -437,7 +437,7 @@ static int code_finish (CoderWs& W, const lh264_code_stream_t* streams_dev, int 
   hipLaunchKernelGGL (lh264::coder_range_walk_kernel, dim3 ((unsigned) ((W.coarse_bound + 63) / 64)), dim3 (64), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs,
                       W.cand, W.seed, chunk_rec, W.coarse_bits);
   HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_range_scan_kernel, dim3 ((unsigned) ((n_pairs + 3) / 4)), dim3 (256), 0, st, W.pair_coarse0, n_pairs, W.coarse_bits, pair_bits);
+  hipLaunchKernelGGL (lh264::coder_range_scan_kernel, dim3 ((unsigned) ((n_pairs + 3) / 4)), dim3 (256), 0, st, W.pair_coarse0, n_pairs, W.coarse_bits, pair_bits, info, Q, acc);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_accum_kernel, dim3 ((unsigned) ((chunk_bound + 255) / 256)), dim3 (256), 0, st, info, Q, pair_chunk0, W.pair_coarse0, n_pairs,
                       chunk_rec, W.coarse_bits, pair_bits, acc);

@@ -1589,7 +1589,8 @@ coder_range_walk_kernel (const uint32_t* __restrict__ chain_info, const uint16_t
 // running sum of the bits over a pair's coarse chunks: coarse_bits[G] becomes the bits shifted out in front of coarse chunk G,
 // pair_bits[pair] all the bits the list shifts out
 __global__ void __launch_bounds__ (256)
-coder_range_scan_kernel (const uint32_t* __restrict__ pair_coarse0, int n_pairs, uint32_t* __restrict__ coarse_bits, uint32_t* __restrict__ pair_bits) {
+coder_range_scan_kernel (const uint32_t* __restrict__ pair_coarse0, int n_pairs, uint32_t* __restrict__ coarse_bits, uint32_t* __restrict__ pair_bits,
+                         const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, uint32_t* __restrict__ acc) {
   const uint32_t pair = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (pair >= (uint32_t)n_pairs) return;
   const uint32_t G0 = pair_coarse0[pair], G1 = pair_coarse0[pair + 1];
@@ -1601,6 +1602,14 @@ coder_range_scan_kernel (const uint32_t* __restrict__ pair_coarse0, int n_pairs,
     carry += (uint32_t)__builtin_amdgcn_readlane ((int)incl, 63);
   }
   if (lane == 0u) pair_bits[pair] = carry;
+  // the pair's sums start at zero - the positions its bits reach, not the whole bound of one position per list entry (that was a 23 GB
+  // fill per call on the large batches: 4 ms)
+  const PairInfo P = pair_info (chain_info, Q, pair);
+  if (P.used) {
+    GLB uint32_t* A = glb<uint32_t> (acc) + P.acc0;
+    const uint32_t n = (carry >> 3) + 8u;
+    for (uint32_t k = lane; k < n; k += 64u) A[k] = 0u;
+  }
 }
 
 // kernel 8: the addends of every chunk into the sums of the output byte positions.  A position takes addends from the decisions that
