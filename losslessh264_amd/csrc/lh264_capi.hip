@@ -332,7 +332,7 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   unsigned long long* totals = (unsigned long long*) (sm + o_totals); uint32_t* seg_doff = (uint32_t*) (sm + o_doff); uint32_t* seg_cnt = (uint32_t*) (sm + o_cnt);
   uint32_t* seg_part = (uint32_t*) (sm + o_part); uint32_t* seg_job = (uint32_t*) (sm + o_sjob);
   uint32_t* seg_bkt = (uint32_t*) (sm + o_bkt); uint8_t* chain_map = sm + o_map;     // decisions per bucket of cells; bucket -> partition
-  const unsigned seg_blocks = (unsigned) ((seg_bound + 3) / 4);
+  const unsigned seg_blocks = (unsigned) ((seg_bound + LH264_CODER_WG_WAVES - 1) / LH264_CODER_WG_WAVES), seg_threads = 64 * LH264_CODER_WG_WAVES;
   if (sw) {
     hipLaunchKernelGGL (lh264sw::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, seg0, job_chain, info);
     HIPCHK (hipGetLastError());
@@ -348,14 +348,14 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
     hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, (unsigned)seg_bound, seg0, seg_job, job_chain, info);
     HIPCHK (hipGetLastError());
     if (n_jobs > 0 && total_mbs > 0) {
-      hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, n_jobs, seg_cnt, seg_bkt);
+      hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 (seg_blocks), dim3 (seg_threads), 0, st, jobs_dev, seg0, seg_job, n_jobs, seg_cnt, seg_bkt);
       HIPCHK (hipGetLastError());
     }
     // the stream's partitions: its buckets of cells dealt out evenly; then where each partition's run starts in every segment
     hipLaunchKernelGGL (lh264::coder_balance_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_bkt, n_chains, log2p, chain_map);
     HIPCHK (hipGetLastError());
     if (n_jobs > 0 && total_mbs > 0) {
-      hipLaunchKernelGGL (lh264::coder_partoff_kernel, dim3 (seg_blocks), dim3 (256), 0, st, seg0, seg_job, job_chain, n_jobs, log2p, seg_bkt, chain_map, seg_part);
+      hipLaunchKernelGGL (lh264::coder_partoff_kernel, dim3 (seg_blocks), dim3 (seg_threads), 0, st, seg0, seg_job, job_chain, n_jobs, log2p, seg_bkt, chain_map, seg_part);
       HIPCHK (hipGetLastError());
     }
     hipLaunchKernelGGL (lh264::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_cnt, seg_doff, info, n_chains);
@@ -392,7 +392,7 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   if (const char* e = getenv ("LH264_CODER_WINDOW")) W.window = atoi (e);      // (experiments; 0: the waves run free)
   if (n_jobs > 0 && total_mbs > 0) {
     if (sw) hipLaunchKernelGGL (lh264sw::coder_emit_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, job_chain, n_jobs, seg_doff, info, D);
-    else hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 (seg_blocks), dim3 (256), 0, st, jobs_dev, seg0, seg_job, job_chain, n_jobs, log2p, seg_doff, seg_cnt, seg_part, chain_map, info, D);
+    else hipLaunchKernelGGL (lh264::coder_emit_kernel, dim3 (seg_blocks), dim3 (seg_threads), 0, st, jobs_dev, seg0, seg_job, job_chain, n_jobs, log2p, seg_doff, seg_cnt, seg_part, chain_map, info, D);
     HIPCHK (hipGetLastError());
   }
   W.info = info; W.D = D; W.Q = Q; W.pair_chunk0 = pair_chunk0; W.pair_bits = pair_bits; W.chunk_rec = chunk_rec; W.acc = acc;
@@ -411,7 +411,8 @@ static int code_finish (CoderWs& W, const lh264_code_stream_t* streams_dev, int 
   if (W.enter (st)) return fail (LH264_E_HIP, "hipStreamWaitEvent (coder work memory)");
   if (!W.sw && W.progress) HIPCHK (hipMemsetAsync (W.progress, 0, ((size_t)n_chains << W.log2p) * 4, st));
   if (W.sw) hipLaunchKernelGGL (lh264sw::coder_resolve_kernel, dim3 (n_chains), dim3 (LH264_CODER_RESOLVE_THREADS), 0, st, streams_dev, info, D, Q, n_chains);
-  else hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 ((unsigned) ((((size_t)n_chains + 7) / 8) * 8 * (((size_t)1 << W.log2p) >= 4 ? ((size_t)1 << W.log2p) / 4 : 1))), dim3 (256), 0, st, streams_dev, info, W.seg0, W.chain_first,
+  else hipLaunchKernelGGL (lh264::coder_resolve_kernel, dim3 ((unsigned) ((((size_t)n_chains + 7) / 8) * 8 * (((size_t)1 << W.log2p) >= LH264_CODER_WG_WAVES ? ((size_t)1 << W.log2p) / LH264_CODER_WG_WAVES : 1))), dim3 (64 * LH264_CODER_WG_WAVES), 0, st,
+                           streams_dev, info, W.seg0, W.chain_first,
                            W.seg_doff, W.seg_part, D, Q, n_chains, W.log2p, W.progress, W.window);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_status_kernel, dim3 ((n_chains + 255) / 256), dim3 (256), 0, st, streams_dev, info, n_chains);

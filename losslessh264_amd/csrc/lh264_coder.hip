@@ -483,14 +483,14 @@ __device__ __forceinline__ uint32_t sym_key (uint32_t prior, int kind) {
   default: return prior;
   }
 }
-__global__ void __launch_bounds__ (256)
+__global__ void __launch_bounds__ (64 * LH264_CODER_WG_WAVES)
 coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ seg_job, int n_jobs,
                     uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_bkt) {
   const int log2p = CODER_LOG2_BUCKETS;            // (the cells are counted per bucket; coder_balance_kernel makes partitions of the buckets)
-  __shared__ CountLds Lg[4];
+  __shared__ CountLds Lg[LH264_CODER_WG_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   LDS CountLds& L = * (LDS CountLds*) (uintptr_t) (uint32_t) (uintptr_t)&Lg[wave];
-  const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
+  const uint32_t seg = blockIdx.x * (uint32_t)LH264_CODER_WG_WAVES + (uint32_t)wave;
   Seg S;
   if (!seg_locate (jobs, seg0, seg_job, n_jobs, seg, S)) return;
   for (int i = lane; i < CNT_SLOTS * 32; i += 64) L.col[i] = 0;
@@ -630,12 +630,12 @@ coder_balance_kernel (const uint32_t* __restrict__ seg0, const int32_t* __restri
 
 // ---- kernel 1c: where each partition's run starts inside a segment's decision words ------------------------------------------------------
 // seg_part[segment][p] = decisions of the segment in partitions < p ([P]: all).  One wave per segment.
-__global__ void __launch_bounds__ (256)
+__global__ void __launch_bounds__ (64 * LH264_CODER_WG_WAVES)
 coder_partoff_kernel (const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ seg_job, const uint32_t* __restrict__ job_chain, int n_jobs, int log2p,
                       const uint32_t* __restrict__ seg_bkt, const uint8_t* __restrict__ chain_map, uint32_t* __restrict__ seg_part) {
-  __shared__ uint32_t pc[4][LH264_CODER_MAX_PARTS];
+  __shared__ uint32_t pc[LH264_CODER_WG_WAVES][LH264_CODER_MAX_PARTS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
+  const uint32_t seg = blockIdx.x * (uint32_t)LH264_CODER_WG_WAVES + (uint32_t)wave;
   if (seg >= seg0[n_jobs]) return;
   LDS uint32_t* pcnt = (LDS uint32_t*) (uintptr_t) (uint32_t) (uintptr_t)&pc[wave][0];
   const int P = 1 << log2p;
@@ -760,14 +760,14 @@ struct EmitLds {
   uint32_t pcur[LH264_CODER_MAX_PARTS];   // next word of each partition's run (within the segment's words)
   uint32_t map[CODER_BUCKETS / 4];        // bucket of cells -> partition (a byte each)
 };
-__global__ void __launch_bounds__ (256)
+__global__ void __launch_bounds__ (64 * LH264_CODER_WG_WAVES)
 coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ seg_job, const uint32_t* __restrict__ job_chain,
                    int n_jobs, int log2p, const uint32_t* __restrict__ seg_doff, const uint32_t* __restrict__ seg_cnt, const uint32_t* __restrict__ seg_part,
                    const uint8_t* __restrict__ chain_map, const uint32_t* __restrict__ chain_info, uint64_t* __restrict__ D) {
-  __shared__ EmitLds Lg[4];
+  __shared__ EmitLds Lg[LH264_CODER_WG_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   LDS EmitLds& L = * (LDS EmitLds*) (uintptr_t) (uint32_t) (uintptr_t)&Lg[wave];
-  const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
+  const uint32_t seg = blockIdx.x * (uint32_t)LH264_CODER_WG_WAVES + (uint32_t)wave;
   Seg S;
   if (!seg_locate (jobs, seg0, seg_job, n_jobs, seg, S)) return;
   seg_layout (L.seg, S, lane);
@@ -847,7 +847,7 @@ coder_emit_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __
 // probability before it halves (DynProb::update, :101-113), so the probability of the next decision always follows from the stored pair,
 // and the halving is done by the next reader.  An entry of the wave's LDS cache (and of the spill table in HBM) is 64 bits: counters in
 // bits 0..19, the DynProb's key (cell key << 4 | place, 36 bits) in bits 20..55, bit 63 set.  All zero = free.
-#define R2_WAVES 4
+#define R2_WAVES LH264_CODER_WG_WAVES
 #define R2_SYNC_EVERY 32u        // rounds between two looks at the other waves of the stream
 #define R2_SYNC_LOOKS 64         // at most this many looks (with a sleep between them) before going on regardless
 #ifndef R2_DMA_MOD
