@@ -303,6 +303,11 @@ def main():
     recon_events = []
     state = {"k": 0, "pipelined": False}
 
+    # the reconstruct kernel is enqueued first: it takes four wave slots of 104 registers on every SIMD, the coder's kernels fit one more
+    # wave beside them.  Enqueued behind the coder's first half, whichever of the two reached a CU first kept it, and a change as small
+    # as a fill kernel more or less moved the step between 26.6 and 34.5 ms (LH264_BENCH_RECON_FIRST=0: that order, for comparison)
+    recon_first = os.environ.get("LH264_BENCH_RECON_FIRST", "1") == "1"
+
     def recon_on_side():
         with torch.cuda.stream(side):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -325,18 +330,24 @@ def main():
             return
         side.wait_stream(cur)   # (the end of the step before)
         if not state["pipelined"]:
+            if recon_first:
+                recon_on_side()
             ctx.run()           # row a8: per-coefficient context-model prior indices
             coder.run()         # rows a9/a10: binarisation, adaptive probabilities, bool coders -> the tagged byte streams
-            recon_on_side()
+            if not recon_first:
+                recon_on_side()
             cur.wait_stream(side)
             return
         i = state["k"] & 1
         j = 1 - i
         state["k"] += 1
         cur.wait_event(ctx_done[i])                 # batch i's context indices (row a8), computed during the step before
+        if recon_first:
+            recon_on_side()                         # rows a1-a7
         coders[i].binarise()                        # rows a9/a10, first half, batch i
         ev_binarised.record(cur)
-        recon_on_side()                             # rows a1-a7
+        if not recon_first:
+            recon_on_side()
         third.wait_event(ev_binarised)
         with torch.cuda.stream(third):
             ctxs[j].run()                           # row a8 of the next batch

@@ -225,7 +225,7 @@ static int ctx_passes (const lh264_ctx_job_t* jobs_dev, const int32_t* chain_fir
   // the compact layout: where every macroblock's symbols go (pictures in the fixed layout count as empty)
   hipLaunchKernelGGL (lh264::ctx_offsets_kernel, dim3 (n_jobs), dim3 (256), 0, st, jobs_dev, n_jobs, (unsigned long long*)W.totals);
   HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::ctx_bases_kernel, dim3 (1), dim3 (1024), 0, st, n_jobs, (unsigned long long*)W.totals, total_dev);
+  hipLaunchKernelGGL (lh264::ctx_bases_kernel, dim3 (1), dim3 (256), 0, st, n_jobs, (unsigned long long*)W.totals, total_dev);
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::ctx_scatter_kernel, dim3 ((unsigned) ((n_jobs + 255) / 256)), dim3 (256), 0, st, jobs_dev, n_jobs, (const unsigned long long*)W.totals);
   HIPCHK (hipGetLastError());
@@ -334,7 +334,7 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   uint32_t* seg_bkt = (uint32_t*) (sm + o_bkt); uint8_t* chain_map = sm + o_map;     // decisions per bucket of cells; bucket -> partition
   const unsigned seg_blocks = (unsigned) ((seg_bound + LH264_CODER_WG_WAVES - 1) / LH264_CODER_WG_WAVES), seg_threads = 64 * LH264_CODER_WG_WAVES;
   if (sw) {
-    hipLaunchKernelGGL (lh264sw::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, seg0, job_chain, info);
+    hipLaunchKernelGGL (lh264sw::coder_jobs_kernel, dim3 (1), dim3 (CODER_ONE_WG), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, seg0, job_chain, info);
     HIPCHK (hipGetLastError());
     if (n_jobs > 0 && total_mbs > 0) {
       hipLaunchKernelGGL (lh264sw::coder_count_kernel, dim3 ((unsigned)seg_bound), dim3 (256), 0, st, jobs_dev, seg0, n_jobs, seg_cnt);
@@ -342,10 +342,10 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
     }
     hipLaunchKernelGGL (lh264sw::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_cnt, seg_doff, info, n_chains);
     HIPCHK (hipGetLastError());
-    hipLaunchKernelGGL (lh264sw::coder_bases_kernel, dim3 (1), dim3 (1024), 0, st, info, n_chains, totals);
+    hipLaunchKernelGGL (lh264sw::coder_bases_kernel, dim3 (1), dim3 (CODER_ONE_WG), 0, st, info, n_chains, totals);
     HIPCHK (hipGetLastError());
   } else {
-    hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (1024), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, (unsigned)seg_bound, seg0, seg_job, job_chain, info);
+    hipLaunchKernelGGL (lh264::coder_jobs_kernel, dim3 (1), dim3 (CODER_ONE_WG), 0, st, jobs_dev, chain_first_dev, n_jobs, n_chains, (unsigned)seg_bound, seg0, seg_job, job_chain, info);
     HIPCHK (hipGetLastError());
     if (n_jobs > 0 && total_mbs > 0) {
       hipLaunchKernelGGL (lh264::coder_count_kernel, dim3 (seg_blocks), dim3 (seg_threads), 0, st, jobs_dev, seg0, seg_job, n_jobs, seg_cnt, seg_bkt);
@@ -360,7 +360,7 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
     }
     hipLaunchKernelGGL (lh264::coder_scan_kernel, dim3 (n_chains), dim3 (64), 0, st, seg0, chain_first_dev, seg_cnt, seg_doff, info, n_chains);
     HIPCHK (hipGetLastError());
-    hipLaunchKernelGGL (lh264::coder_bases_kernel, dim3 (1), dim3 (1024), 0, st, info, n_chains, totals);
+    hipLaunchKernelGGL (lh264::coder_bases_kernel, dim3 (1), dim3 (CODER_ONE_WG), 0, st, info, n_chains, totals);
     HIPCHK (hipGetLastError());
   }
   // the sizes of the decision words and of the tag lists are only known now
@@ -417,7 +417,7 @@ static int code_finish (CoderWs& W, const lh264_code_stream_t* streams_dev, int 
   HIPCHK (hipGetLastError());
   hipLaunchKernelGGL (lh264::coder_status_kernel, dim3 ((n_chains + 255) / 256), dim3 (256), 0, st, streams_dev, info, n_chains);
   HIPCHK (hipGetLastError());
-  hipLaunchKernelGGL (lh264::coder_chunkmap_kernel, dim3 (1), dim3 (1024), 0, st, info, n_pairs, pair_chunk0, W.pair_coarse0, W.cand_list);
+  hipLaunchKernelGGL (lh264::coder_chunkmap_kernel, dim3 (1), dim3 (CODER_ONE_WG), 0, st, info, n_pairs, pair_chunk0, W.pair_coarse0, W.cand_list);
   HIPCHK (hipGetLastError());
   // the bool coders' range recurrence in coarse chunks: start states by lookback, the walk, the running sum of the bits.
   // Lists up to long_list decisions are walked whole by one lane: with many moderate streams (the QCIF batch: 0.7 M decisions a stream)

@@ -57,4 +57,9 @@
 #define LH264_CODER_WG_WAVES 4
 #endif
 
+// threads of the one-workgroup kernels (running sums over pictures, streams, pairs).  A wave per SIMD, not four: these kernels sit in
+// the middle of the coder's chain, and beside the reconstruct kernel of the next batch (four waves of 104 registers on every SIMD)
+// there is room for ONE more wave per SIMD - a workgroup of 1,024 threads waited milliseconds for a CU to come free
+#define CODER_ONE_WG 256
+
 #endif

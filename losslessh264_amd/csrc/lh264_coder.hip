@@ -420,7 +420,7 @@ __device__ __forceinline__ void seg_symbol4 (const LDS SegLds& L, const Seg& S, 
 }
 
 // ---- kernel 0: segments before each picture; which stream a picture belongs to ----------------------------------------------------
-__global__ void __launch_bounds__ (1024)
+__global__ void __launch_bounds__ (CODER_ONE_WG)
 coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __restrict__ chain_first, int n_jobs, int n_chains, unsigned seg_bound,
                    uint32_t* __restrict__ seg0, uint32_t* __restrict__ seg_job, uint32_t* __restrict__ job_chain, uint32_t* __restrict__ chain_info) {
   __shared__ uint32_t wsum[16];
@@ -428,7 +428,7 @@ coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry = 0;
   __syncthreads();
-  for (int j0 = 0; j0 < n_jobs; j0 += 1024) {
+  for (int j0 = 0; j0 < n_jobs; j0 += CODER_ONE_WG) {
     const int j = j0 + tid;
     const int v = j < n_jobs ? (max (jobs[j].n_mbs, 0) + CODER_SEG - 1) / CODER_SEG : 0;
     const int incl = wave_scan_add (v);
@@ -441,13 +441,13 @@ coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __r
       for (uint32_t q = before + (uint32_t) (incl - v); q < before + (uint32_t)incl && q < seg_bound; q++) seg_job[q] = (uint32_t)j;
     }
     __syncthreads();
-    if (tid == 1023) carry = before + (uint32_t)incl;
+    if (tid == CODER_ONE_WG - 1) carry = before + (uint32_t)incl;
     __syncthreads();
   }
   if (tid == 0) seg0[n_jobs] = carry;
   // more segments than the caller's total_mbs made room for: the grids of the segment kernels would not reach all of them
   const uint32_t st0 = carry > seg_bound ? (uint32_t)LH264_CODER_ST_COUNT : 0u;
-  for (int c = tid; c < n_chains; c += 1024) {
+  for (int c = tid; c < n_chains; c += CODER_ONE_WG) {
     for (int j = chain_first[c]; j < chain_first[c + 1]; j++) job_chain[j] = (uint32_t)c;
     chain_info[(size_t)c * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS] = st0;
     for (int q = 90; q < 96; q++) chain_info[(size_t)c * LH264_CODER_INFO_WORDS + q] = 0;
@@ -696,14 +696,14 @@ coder_scan_kernel (const uint32_t* __restrict__ seg0, const int32_t* __restrict_
 }
 
 // ---- kernel 3: where each stream's decision words and tag lists start (prefix over the streams); the totals for the host -------
-__global__ void __launch_bounds__ (1024)
+__global__ void __launch_bounds__ (CODER_ONE_WG)
 coder_bases_kernel (uint32_t* __restrict__ chain_info, int n_chains, unsigned long long* __restrict__ totals) {
   __shared__ unsigned long long wd[16], wq[16];
   __shared__ unsigned long long cd, cq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { cd = 0; cq = 0; }
   __syncthreads();
-  for (int c0 = 0; c0 < n_chains; c0 += 1024) {
+  for (int c0 = 0; c0 < n_chains; c0 += CODER_ONE_WG) {
     const int c = c0 + tid;
     uint32_t* I = chain_info + (size_t) (c < n_chains ? c : 0) * LH264_CODER_INFO_WORDS;
     // a stream's decision words start on a 256-byte line; one spare wave step of words is readable behind them
@@ -724,7 +724,7 @@ coder_bases_kernel (uint32_t* __restrict__ chain_info, int n_chains, unsigned lo
       I[LH264_CODER_INFO_QBASE] = (uint32_t)q0; I[LH264_CODER_INFO_QBASE + 1] = (uint32_t) (q0 >> 32);
     }
     __syncthreads();
-    if (tid == 1023) { cd = bd + sd; cq = bq + sq; }
+    if (tid == CODER_ONE_WG - 1) { cd = bd + sd; cq = bq + sq; }
     __syncthreads();
   }
   if (tid == 0) { totals[0] = cd; totals[1] = cq; }
@@ -1296,7 +1296,7 @@ __device__ __forceinline__ PairInfo pair_info (const uint32_t* chain_info, const
 }
 
 // kernel 6: chunks per (stream, tag) pair and their running sum (one workgroup)
-__global__ void __launch_bounds__ (1024)
+__global__ void __launch_bounds__ (CODER_ONE_WG)
 coder_chunkmap_kernel (const uint32_t* __restrict__ chain_info, int n_pairs, uint32_t* __restrict__ pair_chunk0, uint32_t* __restrict__ pair_coarse0, uint32_t* __restrict__ cand_list) {
   if (threadIdx.x == 0) cand_list[0] = 0;                  // the walks from candidate start states the seed kernel will ask for
   __shared__ uint32_t wsum[16], wsum2[16];
@@ -1304,7 +1304,7 @@ coder_chunkmap_kernel (const uint32_t* __restrict__ chain_info, int n_pairs, uin
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { carry = 0; carry2 = 0; }
   __syncthreads();
-  for (int p0 = 0; p0 < n_pairs; p0 += 1024) {
+  for (int p0 = 0; p0 < n_pairs; p0 += CODER_ONE_WG) {
     const int p = p0 + tid;
     uint32_t v = 0, v2 = 0;
     if (p < n_pairs) {
@@ -1321,7 +1321,7 @@ coder_chunkmap_kernel (const uint32_t* __restrict__ chain_info, int n_pairs, uin
     for (int w = 0; w < wave; w++) { before += wsum[w]; before2 += wsum2[w]; }
     if (p < n_pairs) { pair_chunk0[p] = before + incl - v; pair_coarse0[p] = before2 + incl2 - v2; }
     __syncthreads();
-    if (tid == 1023) { carry = before + incl; carry2 = before2 + incl2; }
+    if (tid == CODER_ONE_WG - 1) { carry = before + incl; carry2 = before2 + incl2; }
     __syncthreads();
   }
   if (tid == 0) { pair_chunk0[n_pairs] = carry; pair_coarse0[n_pairs] = carry2; }

@@ -334,7 +334,7 @@ __device__ __forceinline__ uint64_t seg_symbol (const LDS SegLds& L, const Seg& 
 }
 
 // ---- kernel 0: segments before each picture; which stream a picture belongs to ----------------------------------------------------
-__global__ void __launch_bounds__ (1024)
+__global__ void __launch_bounds__ (CODER_ONE_WG)
 coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __restrict__ chain_first, int n_jobs, int n_chains,
                    uint32_t* __restrict__ seg0, uint32_t* __restrict__ job_chain, uint32_t* __restrict__ chain_info) {
   __shared__ uint32_t wsum[16];
@@ -342,7 +342,7 @@ coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry = 0;
   __syncthreads();
-  for (int j0 = 0; j0 < n_jobs; j0 += 1024) {
+  for (int j0 = 0; j0 < n_jobs; j0 += CODER_ONE_WG) {
     const int j = j0 + tid;
     const int v = j < n_jobs ? (max (jobs[j].n_mbs, 0) + CODER_SEG - 1) / CODER_SEG : 0;
     const int incl = wave_scan_add (v);
@@ -352,11 +352,11 @@ coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __r
     for (int w = 0; w < wave; w++) before += wsum[w];
     if (j < n_jobs) seg0[j] = before + (uint32_t) (incl - v);
     __syncthreads();
-    if (tid == 1023) carry = before + (uint32_t)incl;
+    if (tid == CODER_ONE_WG - 1) carry = before + (uint32_t)incl;
     __syncthreads();
   }
   if (tid == 0) seg0[n_jobs] = carry;
-  for (int c = tid; c < n_chains; c += 1024) {
+  for (int c = tid; c < n_chains; c += CODER_ONE_WG) {
     for (int j = chain_first[c]; j < chain_first[c + 1]; j++) job_chain[j] = (uint32_t)c;
     chain_info[(size_t)c * LH264_CODER_INFO_WORDS + LH264_CODER_INFO_STATUS] = 0;
     for (int q = 90; q < 96; q++) chain_info[(size_t)c * LH264_CODER_INFO_WORDS + q] = 0;
@@ -428,14 +428,14 @@ coder_scan_kernel (const uint32_t* __restrict__ seg0, const int32_t* __restrict_
 }
 
 // ---- kernel 3: where each stream's decision words and tag lists start (prefix over the streams); the totals for the host -------
-__global__ void __launch_bounds__ (1024)
+__global__ void __launch_bounds__ (CODER_ONE_WG)
 coder_bases_kernel (uint32_t* __restrict__ chain_info, int n_chains, unsigned long long* __restrict__ totals) {
   __shared__ unsigned long long wd[16], wq[16];
   __shared__ unsigned long long cd, cq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { cd = 0; cq = 0; }
   __syncthreads();
-  for (int c0 = 0; c0 < n_chains; c0 += 1024) {
+  for (int c0 = 0; c0 < n_chains; c0 += CODER_ONE_WG) {
     const int c = c0 + tid;
     uint32_t* I = chain_info + (size_t) (c < n_chains ? c : 0) * LH264_CODER_INFO_WORDS;
     // a stream's decision words start on a 256-byte line; one spare wave step of words is readable behind them
@@ -456,7 +456,7 @@ coder_bases_kernel (uint32_t* __restrict__ chain_info, int n_chains, unsigned lo
       I[LH264_CODER_INFO_QBASE] = (uint32_t)q0; I[LH264_CODER_INFO_QBASE + 1] = (uint32_t) (q0 >> 32);
     }
     __syncthreads();
-    if (tid == 1023) { cd = bd + sd; cq = bq + sq; }
+    if (tid == CODER_ONE_WG - 1) { cd = bd + sd; cq = bq + sq; }
     __syncthreads();
   }
   if (tid == 0) { totals[0] = cd; totals[1] = cq; }

@@ -241,13 +241,16 @@ ctx_offsets_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, unsign
   }
   if (tid == 0) job_total[ji] = carry;
 }
-__global__ void __launch_bounds__ (1024)
+// (a wave per SIMD: beside the reconstruct kernel of the next batch there is room for one more wave per SIMD, and this kernel sits in
+// the middle of the chain - with 1,024 threads it waited for a CU to come free)
+#define CTX_ONE_WG 256
+__global__ void __launch_bounds__ (CTX_ONE_WG)
 ctx_bases_kernel (int n_jobs, unsigned long long* __restrict__ job_total, unsigned long long* __restrict__ total) {
   __shared__ unsigned long long wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // every thread a run of consecutive pictures: its sum, the running sum over the threads, then the run again.  job_total[j] becomes
   // the symbols in front of picture j (ctx_scatter_kernel hands them to the jobs)
-  const int per = (n_jobs + 1023) / 1024, j0 = min (tid * per, n_jobs), j1 = min (j0 + per, n_jobs);
+  const int per = (n_jobs + CTX_ONE_WG - 1) / CTX_ONE_WG, j0 = min (tid * per, n_jobs), j1 = min (j0 + per, n_jobs);
   unsigned long long mine = 0;
   for (int j = j0; j < j1; j++) mine += job_total[j];
   unsigned long long incl = mine;
@@ -257,7 +260,7 @@ ctx_bases_kernel (int n_jobs, unsigned long long* __restrict__ job_total, unsign
   unsigned long long at = incl - mine;
   for (int w = 0; w < wave; w++) at += wsum[w];
   for (int j = j0; j < j1; j++) { const unsigned long long v = job_total[j]; job_total[j] = at; at += v; }
-  if (tid == 1023) { job_total[n_jobs] = at; if (total) *total = at; }
+  if (tid == CTX_ONE_WG - 1) { job_total[n_jobs] = at; if (total) *total = at; }
 }
 __global__ void __launch_bounds__ (256)
 ctx_scatter_kernel (const lh264_ctx_job_t* __restrict__ jobs, int n_jobs, const unsigned long long* __restrict__ job_total) {
