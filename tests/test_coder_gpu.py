@@ -42,6 +42,40 @@ def test_device_coder_equals_reference_bytes(path, monkeypatch):
             assert got[t] == refs[c][t], "%s tag %d: %d bytes, reference %d" % (name, t, len(got[t]), len(refs[c][t]))
 
 
+@pytest.mark.parametrize("log2p,window", [(0, 3), (2, 0), (4, 1), (5, 3), (7, 0)])
+def test_wave_form_partitions_and_window_do_not_change_the_bytes(log2p, window, monkeypatch):
+    """the wave form with 1 .. 128 partitions per stream (buckets of cells dealt to the partitions by coder_balance_kernel; 128 = the
+    buckets themselves) and with / without the hint that keeps a stream's waves together: ten streams, so that the workgroups of the
+    resolve kernel cover every XCD residue and a second group of eight - every tag byte-identical to the reference's"""
+    import ctypes as C
+    import losslessh264_amd as lh
+    from losslessh264_amd import _lib as L
+    monkeypatch.setenv("LH264_CODER_PATH", "wave")
+    monkeypatch.setenv("LH264_CODER_LOG2P", str(log2p))
+    monkeypatch.setenv("LH264_CODER_WINDOW", str(window))
+    streams, refs = [], []
+    for name in FIXTURES:
+        z = np.load(os.path.join(golden_io.GOLDEN_DIR, "pip_" + name + ".npz"))
+        streams.append(_frames(name, z))
+        refs.append({int(k[4:]): z[k].tobytes() for k in z.files if k.startswith("tag_")})
+    ctx = lh.CtxSession(streams)
+    ctx.run()
+    coder = lh.CoderSession(ctx, out_cap=1 << 17)
+    coder.run()
+    ctx.synchronize()
+    for c, name in enumerate(FIXTURES):
+        assert coder.tags(c) == refs[c], name
+    # the partitions of the first stream: as many as asked for, and between them every decision of the stream
+    f = L.lib().lh264_debug_coder_parts
+    f.restype = C.c_int
+    out = (C.c_ulonglong * 128)()
+    assert f(0, out, 128) == 1 << log2p
+    parts = [out[i] for i in range(1 << log2p)]
+    assert sum(parts) > 0
+    if log2p == 4:
+        assert max(parts) * 16 <= 2 * sum(parts), parts          # dealt evenly (a small stream: within 2x of the mean)
+
+
 def test_replicas_are_identical_and_rerun_is_stable():
     import losslessh264_amd as lh
     name = "SVA_BA2_D.264"
