@@ -313,7 +313,9 @@ static int code_binarise (CoderWs& W, const lh264_code_job_t* jobs_dev, const in
   // the partitions of a stream's DynProbs (each resolved by a wave of its own): as few as fill the machine with waves - a partition's
   // runs of decision words get shorter with their number, and a run costs its wave a look at the segment tables
   // (LH264_CODER_LOG2P overrides, for experiments)
-  int log2p = n_chains >= 512 ? 3 : 4;      // (measured: 256 x 16 beats 256 x 32; 512 x 8 beats 512 x 16 - 4.9 against 6.6 ms; 1,024 x 8 and 2,048 x 8 beat x 4)
+  // (measured: 256 x 16 beats 256 x 8 and x 32 - 40 against 60 and 54 ms on the 1080p batch; 512 x 8 beats 512 x 16 on QCIF streams -
+  // 4.9 against 6.6 ms -, 1,024 x 8 beats x 16 on CIF streams - 4.6 against 5.6 -, but 1,024 x 16 beats x 8 on 720p streams - 33 against 36)
+  int log2p = (n_chains >= 512 && total_mbs / n_chains <= 12288) ? 3 : 4;
   while (log2p < LH264_CODER_MAX_LOG2P && ((long long)n_chains << log2p) < 2048) log2p++;
   if (const char* e = getenv ("LH264_CODER_LOG2P")) { const int v = atoi (e); if (v >= 0 && v <= LH264_CODER_MAX_LOG2P) log2p = v; }
   W.log2p = log2p;

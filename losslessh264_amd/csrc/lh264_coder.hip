@@ -1425,6 +1425,7 @@ struct RangeWalk {
     for (int q = 0; q < 8; q++) pos += code_step (range, w[q >> 1] >> (16 * (q & 1))).shift;
   }
 };
+#define ACC_WIN 2048u         // positions of the accumulate kernel's LDS window per wave
 #define CODE_AHEAD 8u        // 16-byte pieces of the list under way per lane
 // the walk of coarse chunk G from state s0, on through the unresolved chunks behind it.  NOTES: the final walk (chunk_rec, coarse_bits);
 // otherwise only the state the walk ends with is wanted.  resolved[2 * G] != 0 <=> chunk G has candidates (a lane of its own).
@@ -1619,8 +1620,18 @@ __global__ void __launch_bounds__ (256)
 coder_accum_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __restrict__ Q, const uint32_t* __restrict__ pair_chunk0,
                     const uint32_t* __restrict__ pair_coarse0, int n_pairs,
                     const uint32_t* __restrict__ chunk_rec, const uint32_t* __restrict__ coarse_bits, const uint32_t* __restrict__ pair_bits, uint32_t* __restrict__ acc) {
-  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-  if (g >= pair_chunk0[n_pairs]) return;
+  // The sums of a wave's 64 chunks fall on a few thousand consecutive positions (the chunks follow one another in a list).  Stored one
+  // by one they were 4-byte pieces a lane apart - 15 GB written for under 2 GB of sums; they are collected in a window of the wave's LDS
+  // (positions relative to its first chunk's; what falls outside, or belongs to another list, goes to memory as before) and added to
+  // memory at the end, 64 consecutive positions an instruction.
+  __shared__ uint32_t wing[4][ACC_WIN];
+  const uint32_t lane = threadIdx.x & 63u;
+  LDS uint32_t* win = (LDS uint32_t*) (uintptr_t) (uint32_t) (uintptr_t)&wing[threadIdx.x >> 6][0];
+  const uint32_t g_raw = blockIdx.x * 256u + threadIdx.x, n_chunks = pair_chunk0[n_pairs];
+  if ((uint32_t)__builtin_amdgcn_readfirstlane ((int)g_raw) >= n_chunks) return;      // (lane 0 has the wave's first chunk: the whole wave is beyond the last one)
+  for (uint32_t i = lane * 4u; i < ACC_WIN; i += 256u) { u32x4 z = {0u, 0u, 0u, 0u}; * (LDS u32x4*) (win + i) = z; }
+  const bool live = g_raw < n_chunks;
+  const uint32_t g = live ? g_raw : n_chunks - 1u;          // (a lane beyond the last chunk: reads that chunk's tables, adds nothing)
   uint32_t range = chunk_rec[2 * (size_t)g], t = chunk_rec[2 * (size_t)g + 1];
   const uint32_t pair = range >> 8;
   range &= 0xffu;
@@ -1633,12 +1644,15 @@ coder_accum_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __r
                                                         : pair_bits[pair];     // where the next chunk starts
   const uint32_t own_lo = (t >> 3) + 2u, own_hi = t_end >> 3;            // positions own_lo .. own_hi - 1 are this chunk's alone
   GLB uint32_t* A = glb<uint32_t> (acc) + P.acc0;
+  const uint32_t pair0 = (uint32_t)__builtin_amdgcn_readfirstlane ((int)pair), base0 = (uint32_t)__builtin_amdgcn_readfirstlane ((int) (t >> 3));
+  const bool same = pair == pair0;
+  wsync();
   auto put = [&] (uint32_t kpos, uint32_t v) {
-    if (v == 0u) return;
-#ifndef LH264_ABL_CODE_NOATOMIC     // timing ablation only (wrong output)
-    if (kpos >= own_lo && kpos < own_hi) A[kpos] = v;
+    if (v == 0u || !live) return;
+    const uint32_t rel = kpos - base0;
+    if (same && rel < ACC_WIN) __hip_atomic_fetch_add (win + rel, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if (kpos >= own_lo && kpos < own_hi) A[kpos] = v;
     else atomicAdd ((uint32_t*) (uintptr_t) (A + kpos), v);
-#endif
   };
   // window: the addends at byte position kb (bits 8 and up of w) and kb + 1 (bits 0..7); an addend starts t bits behind the list's first bit
   uint32_t kb = t >> 3, w = 0;
@@ -1684,6 +1698,16 @@ coder_accum_kernel (const uint32_t* __restrict__ chain_info, const uint16_t* __r
   for (uint32_t i = max (i0, c1 * 8u); i < i1; i++) one (L.at (i));
   put (kb, w >> 8);
   put (kb + 1u, w & 0xffu);
+  // the window to memory (added: the positions at either end are shared with the neighbouring waves' windows)
+  uint32_t top = same && live ? min (kb + 2u - base0, (uint32_t)ACC_WIN) : 0u;
+  for (int m = 1; m < 64; m <<= 1) top = max (top, (uint32_t)__shfl_xor ((int)top, m));
+  wsync();
+  GLB uint32_t* A0 = glb<uint32_t> (acc) + ((unsigned long long) (uint32_t)__builtin_amdgcn_readfirstlane ((int) (uint32_t)P.acc0) |
+                                             (unsigned long long) (uint32_t)__builtin_amdgcn_readfirstlane ((int) (uint32_t) (P.acc0 >> 32)) << 32) + base0;
+  for (uint32_t i = lane; i < top; i += 64u) {
+    const uint32_t v = * (volatile LDS uint32_t*) (win + i);
+    if (v) atomicAdd ((uint32_t*) (uintptr_t) (A0 + i), v);
+  }
 }
 
 // kernel 9: carries, bytes, lengths.  vpx_write puts a byte out whenever 8 more bits have been shifted out beyond the first 24:
