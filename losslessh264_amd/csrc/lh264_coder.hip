@@ -4,24 +4,30 @@
 // emitBitsZeroToPow2Inclusive, /root/reference/codec/decoder/core/inc/compression_stream.h:117-166,455-591) -> per decision an
 // adaptive probability (DynProb :87-115) -> the libvpx bool coder of the decision's tag (bitwriter.h:35-105).  Only two things in
 // that chain are really sequential: the state of ONE DynProb over the decisions made with it, and the state of ONE tag's bool coder
-// over the decisions sent to it.  Everything else is data parallel, so the work is cut into kernels along those two lines:
+// over the decisions sent to it.  Everything else is data parallel, so the work is cut into kernels along those two lines.  This file
+// is the form that scales INSIDE a stream (round 3); lh264_coder_sw.hip keeps round 2's first stages (a stream per workgroup), and
+// lh264_capi.hip:code_binarise picks one per call.  Launch order:
 //
-//   coder_count_kernel    per segment (<= 128 consecutive macroblocks of a picture), a thread per symbol: the number of decisions
-//                         per tag in closed form (sym_count), summed per segment                                   (parallel)
-//   coder_scan_kernel     per stream: where each segment's decisions start; size of every tag's list               (small)
-//   coder_bases_kernel    prefix over the streams; totals for the host                                              (small)
-//   coder_emit_kernel     per segment, four waves over its flat symbol list: binarise, write one 64-bit word per decision in
-//                         coding order (the key of the DynProb's cell, the place in it, bit, tag slot / raw bit)     (parallel)
-//   coder_resolve_kernel  one workgroup of 8 waves per stream, 64 decisions per wave step: a DynProb is two counters, so the
-//                         probability a decision is coded with follows from the counters before the step and PREFIX COUNTS of
-//                         the earlier decisions of the step on the same DynProb.  Lanes holding the same DynProb find each other
-//                         with ballots (no serial walk); the only serial part is a short ticketed section per step: read the
-//                         counters, write them back.  The counters live in a keyed LDS cache in front of a spill table in HBM.
-//                         Output: (probability of the bit that occurred, bit) appended to the list of the decision's tag.
-//                                                                                                  (serial per stream, 512 wide)
-//   coder_range_kernel    one lane per (stream, tag): the bool coder's range recurrence over that tag's list       (serial per tag)
-//   coder_accum_kernel, coder_bytes_kernel   the bool coder's `low`: addends summed per output byte position by chunks of the list,
-//                         then the carries and the bytes                                                            (parallel)
+//   coder_jobs_kernel         segments (<= 64 consecutive macroblocks of a picture) before every picture; picture -> stream    (small)
+//   coder_count_kernel        a wave per segment, a lane per symbol: decisions per tag and per bucket of cells, in closed form
+//                             (sym_count); the segment's symbols swept as two dense ranges                                  (parallel)
+//   coder_balance_kernel      per stream: its 128 buckets of cells dealt to its 8 / 16 partitions, largest first              (small)
+//   coder_partoff_kernel      per segment: where each partition's run of decision words starts                              (small)
+//   coder_scan_kernel, coder_bases_kernel   where each segment's words and its entries of every tag's list start; stream bases (small)
+//   coder_emit_kernel         a wave per segment, a lane per DECISION: the decision in closed form (decision_at) as a 64-bit word - key
+//                             of the DynProb's cell, place, bit, the entry of its tag's list it will fill - into its partition's run
+//                                                                                                                            (parallel)
+//   coder_resolve_kernel      a wave per (stream, partition), 64 decisions per round: a DynProb is two counters, so the probability
+//                             a decision is coded with follows from the counters before the round and PREFIX COUNTS of the earlier
+//                             decisions of the round on the same DynProb; lanes holding the same DynProb find each other with
+//                             ballots.  Counters in a keyed LDS cache in front of a spill table in HBM.  Output: (probability of
+//                             the bit that occurred, bit) at the word's entry of its tag's list.  A stream's waves share one
+//                             XCD's L2 and keep near one another (the 2-byte entries of a sector come from all of them)
+//                                                                                              (serial per partition, 64 wide)
+//   coder_chunkmap_kernel, coder_range_seed / first / link / walk / scan_kernel   the bool coder's range recurrence per tag list,
+//                             in coarse chunks from checked candidate start states                        (serial per chunk)
+//   coder_accum_kernel, coder_bytes_kernel   the bool coder's `low`: addends summed per output byte position by chunks of the
+//                             list, then the carries and the bytes                                                          (parallel)
 //
 // Halving is lazy: the table holds the un-halved pair of counters and the reader halves when their sum has passed 512, so the
 // probability always follows from the pair; zero-filled memory is the initial state.  See DESIGN.md section 4.3.
@@ -59,58 +65,6 @@ __device__ __forceinline__ uint32_t dp_ratio (uint32_t c0, uint32_t c1) {
 
 __device__ __forceinline__ int tag_slot (int tag) { return tag == 69 ? 34 : tag; }
 
-// ---- binarisation: a symbol becomes a short list of decisions ---------------------------------------------------------------
-// Written once against a sink: sink.cell (key) names the 16-DynProb cell the following decisions use (priors that are trees of
-// more than 16 nodes span several cells), sink.dec (j, bit, tag) is one decision on place j of that cell, j == 0xff a raw bit
-// (coded with the shared TEST_PROB, compression_stream.h:363,441-448), sink.touch (tag) a stream that comes into existence.
-template <class S> __device__ __forceinline__ void bz_unary (S& s, int data, int base, int n, int early, int tag) {   // emitUnary :465-474
-  for (int i = 0; i < data; i++) {
-    s.dec (base + (i < n - 1 ? i : n - 1), 1, tag);
-    if (i == early - 1) return;
-  }
-  s.dec (base + (data < n - 1 ? data : n - 1), 0, tag);
-}
-// emitInt :523-572 with the prior's parts at fixed places of the cell (zero / sign < 0: the prior has none)
-template <class S> __device__ __forceinline__ void bz_int (S& s, int data, int zero, int sign, int ebase, int E, int mbase, int M, int order,
-                                                            int tag_exp, int tag_man, int tag_zero, int tag_sign) {
-  if (zero >= 0) { s.dec (zero, data == 0, tag_zero); if (data == 0) return; }
-  if (sign >= 0) { s.dec (sign, data > 0, tag_sign); if (data < 0) data = -data; }
-  data--;
-  const int data_high = 1 + (data >> order);
-  const int log2 = 31 - __clz (data_high);               // largest l with (1 << l) <= data_high
-  bz_unary (s, log2, ebase, E, -1, tag_exp);
-  int lo = 0, hi = M;
-  const int nb = log2 + order;
-  for (int i = 0; i < nb; i++) {
-    const int bit = i < log2 ? (data_high >> (log2 - 1 - i)) & 1 : (data >> (order - 1 - (i - log2))) & 1;
-    if (hi > lo) {
-      const int mid = (hi + lo) / 2;
-      s.dec (mbase + mid, bit, tag_man);
-      if (bit) lo = mid + 1; else hi = mid;
-    } else s.dec (0xff, bit, tag_man);
-  }
-}
-// emitUEGkInt :575-591; cell: zero 0, sign 1, first 2..2+M-1, second = {zero, exponent[E], mantissa[Mant]}
-template <class S> __device__ __forceinline__ void bz_uegk (S& s, int data, int N, int M, int E, int Mant, int order, int tag_exp, int tag_man, int tag_zero, int tag_sign) {
-  s.dec (0, data == 0, tag_zero);
-  if (data == 0) return;
-  s.dec (1, data < 0, tag_sign);
-  if (data < 0) data = -data;
-  bz_unary (s, data - 1, 2, M, N, tag_man);
-  if (data - 1 >= N) bz_int (s, data - 1 - N, 2 + M, -1, 2 + M + 1, E, 2 + M + 1 + E, Mant, order, tag_exp, tag_man, tag_zero, tag_sign);
-}
-// Branch<nbits> (:117-166): a node's array = itself, its 0-subtree, its 1-subtree.  With more than 16 nodes, node n lives
-// in cell index * groups + n / 16, place n % 16.
-template <class S> __device__ __forceinline__ void bz_tree (S& s, uint32_t prior, int groups, unsigned off, unsigned data, int nbits, int tag) {
-  const uint32_t index = prior & 0x7ffffffu;
-  int cur_group = 0;
-  for (int n = nbits; n >= 1; n--) {
-    const int bit = (data >> (n - 1)) & 1;
-    if (groups > 1 && (int) (off >> 4) != cur_group) { cur_group = (int) (off >> 4); s.cell ((prior & 0xf8000000u) | (index * (uint32_t)groups + (off >> 4))); }
-    s.dec ((int) (off & 15u), bit, tag);
-    off += bit ? 1u + ((1u << (n - 1)) - 1u) : 1u;
-  }
-}
 // the tag of a coefficient / nonzero-count symbol: the context-index kernel leaves it in the symbol's pad byte (lh264_ctx.hip mk_sym);
 // symbols from elsewhere (pad 0) have it taken out of the prior: colour, first scan position and macroblock class (encode4x4)
 __device__ __forceinline__ int ac_tag_base (uint32_t prior, int kind, int pad) {
@@ -122,59 +76,9 @@ __device__ __forceinline__ int ac_tag_base (uint32_t prior, int kind, int pad) {
   return color ? 29 : (first ? 19 : 24);
 }
 __device__ __forceinline__ int nz_tag (uint32_t prior, int pad) { return pad ? pad : (((prior / 27u) % 3u) ? 29 : 19); }
-template <class S> __device__ __forceinline__ void binarize (S& s, uint32_t prior, int value, int kind, int pad) {
-  enum { T_LDC = 17, T_CRDC = 18, T_LAC_0_EOB = 19, T_LAC_N_EOB = 24, T_CRAC_EOB = 29 };
-  const int table = (int) (prior >> 27);
-  const uint32_t index = prior & 0x7ffffffu;
-  switch (kind) {
-  case LH264_SYM_LUMA_DC: case LH264_SYM_CHROMA_DC: {      // IntPrior<3,4>: exponent 0..2, mantissa 3..6, zero 7, sign 8
-    const int t = kind == LH264_SYM_LUMA_DC ? T_LDC : T_CRDC;
-    s.cell (LH264_PRIOR (kind == LH264_SYM_LUMA_DC ? LH264_TB_LDC : LH264_TB_CDC, prior));
-    bz_int (s, value, 7, 8, 0, 3, 3, 4, 0, t, t, t, t);
-    break; }
-  case LH264_SYM_NZ4: case LH264_SYM_NZ8: {                 // UnsignedIntPrior<3,4>
-    const int t = nz_tag (prior, pad);
-    s.cell (LH264_PRIOR (kind == LH264_SYM_NZ4 ? LH264_TB_NZ4 : LH264_TB_NZ8, prior));
-    bz_int (s, value, 7, -1, 0, 3, 3, 4, 0, t, t, t, t);
-    break; }
-  case LH264_SYM_AC4: case LH264_SYM_AC8: {                 // UEGkIntPrior<14,4,2,4,0>; tags by colour / first scan position (encode4x4)
-    const int base = ac_tag_base (prior, kind, pad);
-    s.touch (base + 2);                                      // encode4x4 bills to tag(..._EXP): the stream exists from then on
-    s.cell (LH264_PRIOR (kind == LH264_SYM_AC4 ? LH264_TB_AC4 : LH264_TB_AC8, prior));
-    bz_uegk (s, value, 14, 4, 2, 4, 0, base + 2, base + 3, base + 1, base + 4);
-    break; }
-  case LH264_SYM_BIT:
-    s.cell (prior);
-    s.dec (0, value != 0, pad);
-    break;
-  case LH264_SYM_RAW:
-    for (int i = 0; i < (int)prior; i++) s.dec (0xff, (value >> ((int)prior - 1 - i)) & 1, pad);
-    break;
-  case LH264_SYM_MVD:                                       // UEGkIntPrior<9,4,3,4,3>
-    s.cell (prior);
-    bz_uegk (s, value, 9, 4, 3, 4, 3, pad, pad, pad, pad);
-    break;
-  case LH264_SYM_TREE: {
-    int nbits = 4, groups = 1;
-    if (table == LH264_TB_SKIPRUN) { nbits = 9; groups = 32; } else if (table == LH264_TB_SUBMB) { nbits = 8; groups = 16; }
-    else if (table == LH264_TB_CBPC) nbits = 2;
-    s.cell ((prior & 0xf8000000u) | (index * (uint32_t)groups));        // the cell of the tree's first 16 nodes
-    bz_tree (s, prior, groups, 0, (unsigned) (uint16_t)value, nbits, pad);
-    break; }
-  case LH264_SYM_POW2: {                                    // emitBitsZeroToPow2Inclusive<nbits>: priors[0], then the tree in priors[1..]
-    const bool qpl = table == LH264_TB_QPL;
-    const int groups = qpl ? 8 : 1;
-    const unsigned preferred = qpl ? 0u : index, data = (unsigned) (uint16_t)value;
-    s.cell ((prior & 0xf8000000u) | (index * (uint32_t)groups));
-    s.dec (0, data != preferred, pad);
-    if (data != preferred) bz_tree (s, prior, groups, 1, data > preferred ? data - 1u : data, qpl ? 7 : 3, pad);
-    break; }
-  default: break;
-  }
-}
-
+// the key raw bits are filed under: the shared TEST_PROB (compression_stream.h:363,441-448) as a cell of its own
 #define CODER_RAW_KEY 0xf8000000u
-// ---- how many decisions a symbol becomes, per tag, without walking its binarisation (same cases as binarize above) -------------
+// ---- how many decisions a symbol becomes, per tag, without walking its binarisation (the walk: lh264_coder_sw.hip binarize) -------
 // n: all decisions; up to four (tag slot, count) pairs (-1: unused); tch: tag brought into existence; raws: how many of the decisions are
 // raw bits (the shared TEST_PROB); key: the cell the others use (trees over several cells: the first one).
 // The lanes of a wave hold symbols of all kinds: the integer-like ones (DC, nonzero count, coefficient, motion vector difference -
@@ -234,7 +138,7 @@ template <bool CTX_ONLY = false> __device__ __forceinline__ SymCount sym_count (
   return c;
 }
 
-// ---- decision j of a symbol in closed form (the same cases as binarize / sym_count above, without walking the binarisation) ----
+// ---- decision j of a symbol in closed form (the same cases as sym_count above, without walking the binarisation) ----
 // The parallel binarisation works a lane per DECISION: the j-th decision of a symbol follows from kind, value and j alone.
 // key: the cell of the DynProb (LH264_PRIOR form), place: its place in the cell; raw bits (coded with the shared TEST_PROB,
 // compression_stream.h:363,441-448) carry CODER_RAW_KEY, place 0.
@@ -385,16 +289,6 @@ __device__ __forceinline__ void seg_layout (LDS SegLds& L, Seg& S, int lane) {
 __device__ __forceinline__ size_t ctx_sym_at (const lh264_code_job_t* J, int k) {
   return J->ctx_sym_off_dev ? (size_t)*glb<const unsigned long long> (J->ctx_sym_base_dev) + glb<const uint32_t> (J->ctx_sym_off_dev)[k] : (size_t)k * LH264_CTX_MAX_SYMS;
 }
-// symbol s of the segment (coding order)
-__device__ __forceinline__ uint64_t seg_symbol (const LDS SegLds& L, const Seg& S, uint32_t s) {
-  uint32_t lo = 0, hi = (uint32_t)S.n;                   // the macroblock that holds symbol s
-  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (L.sbase[mid] <= s) lo = mid; else hi = mid; }
-  const uint32_t i = s - L.sbase[lo], p = L.p[lo], mc = p != 0xffffu ? L.mc[lo] : 0u;
-  const GLB uint64_t* hs = glb<const uint64_t> (S.J->syn_syms_dev) + L.hoff[lo];
-  if (i < p || p == 0xffffu) return hs[i];
-  if (i < p + mc) return glb<const uint64_t> (S.J->ctx_syms_dev)[ctx_sym_at (S.J, S.k0 + (int)lo) + (i - p)];
-  return hs[i - mc + 1u];
-}
 // symbols s0 + 64 q + lane, q = 0 .. 3, of the segment (0 beyond its end): the four searches advance together, so that a step waits for
 // LDS once, not four times, and the four loads are under way together
 __device__ __forceinline__ void seg_symbol4 (const LDS SegLds& L, const Seg& S, uint32_t s0, int lane, uint64_t out[4]) {
@@ -461,28 +355,8 @@ coder_jobs_kernel (const lh264_code_job_t* __restrict__ jobs, const int32_t* __r
 // Counters: one 16-bit column per lane in LDS ([slot][lane], two lanes to a dword) - the symbols of a step mostly count towards the
 // same few tags, and 64 lanes adding to one LDS word take 64 turns (that was the round-2 kernel's whole time); a lane's column is
 // its own bank.  A lane sees at most 64 x 528 / 64 symbols of at most 46 decisions: the 16-bit columns cannot overflow.
-// raw decisions behind emitInt's zero flag and sign (the mantissa bits beyond its four priors, man_place < 0)
-__device__ __forceinline__ int int_tail_raws (int data, int order) {
-  const int a = data - 1, high = 1 + (a >> order), l2 = 31 - __clz (high), nb = l2 + order;
-  if (nb <= 2) return 0;
-  auto mbit = [&] (int k) -> int { return k < l2 ? (high >> (l2 - 1 - k)) & 1 : (a >> ((order - 1 - (k - l2)) & 31)) & 1; };
-  return nb - 2 - ((!mbit (0) && !mbit (1)) ? 1 : 0);
-}
 #define CNT_SLOTS (LH264_N_TAG_SLOTS + 1)            // columns: the tag slots, then all decisions
 struct CountLds { SegLds seg; uint32_t col[CNT_SLOTS * 32]; uint32_t pcnt[LH264_CODER_MAX_PARTS]; };
-// the cell the decisions of a symbol use (trees over several cells: the first one), without its binarisation
-__device__ __forceinline__ uint32_t sym_key (uint32_t prior, int kind) {
-  switch (kind) {
-  case LH264_SYM_LUMA_DC: return LH264_PRIOR (LH264_TB_LDC, prior);
-  case LH264_SYM_CHROMA_DC: return LH264_PRIOR (LH264_TB_CDC, prior);
-  case LH264_SYM_NZ4: return LH264_PRIOR (LH264_TB_NZ4, prior);
-  case LH264_SYM_NZ8: return LH264_PRIOR (LH264_TB_NZ8, prior);
-  case LH264_SYM_AC4: return LH264_PRIOR (LH264_TB_AC4, prior);
-  case LH264_SYM_AC8: return LH264_PRIOR (LH264_TB_AC8, prior);
-  case LH264_SYM_RAW: return CODER_RAW_KEY;
-  default: return prior;
-  }
-}
 __global__ void __launch_bounds__ (64 * LH264_CODER_WG_WAVES)
 coder_count_kernel (const lh264_code_job_t* __restrict__ jobs, const uint32_t* __restrict__ seg0, const uint32_t* __restrict__ seg_job, int n_jobs,
                     uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_bkt) {
