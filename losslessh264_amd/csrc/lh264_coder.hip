@@ -1112,15 +1112,16 @@ void read_rs_stamps (unsigned long long* out, bool reset) {
 
 // ---- kernels 6..9: the libvpx bool coder (vpx_writer, bitwriter.h:35-105; vpx_stop_encode bitwriter.cpp:17-37) ----------------
 // vpx_write keeps (low, range, count).  `range` depends only on the decisions so far - a 7-bit state that does not forget where it
-// started (two start values stay apart for hundreds of decisions: measured), so its recurrence is walked once, serially, per
-// (stream, tag); but that walk is all that is serial.  What vpx_write finally writes is one big number: every decision with bit 1
-// adds its `split` (8 bits) at the bit position given by the shifts before it, and carries run towards the first byte.  So:
-//   coder_chunkmap_kernel  chunks (CODE_CHUNK decisions) per (stream, tag) pair, running sum
-//   coder_range_kernel     one lane per pair: the range recurrence alone (no low, no bytes) - mad, two shifts, count-leading-zeros,
-//                          shift per decision -, noting range and bit position at the start of every chunk
+// started (two start values stay apart for hundreds of decisions: measured), so its recurrence has to be walked serially - per
+// coarse chunk of a list, from checked candidate start states (kernel 7 below); but that walk is all that is serial.  What vpx_write
+// finally writes is one big number: every decision with bit 1 adds its `split` (8 bits) at the bit position given by the shifts
+// before it, and carries run towards the first byte.  So:
+//   coder_chunkmap_kernel  chunks (CODE_CHUNK decisions) and coarse chunks per (stream, tag) pair, running sums
+//   coder_range_*_kernel   the range recurrence alone (no low, no bytes) - mad, two shifts, count-leading-zeros, shift per decision -,
+//                          noting range and bit position at the start of every chunk
 //   coder_accum_kernel     one lane per chunk: the recurrence again from the noted state; the addends go into 32-bit sums per output
-//                          byte position (a window in registers, atomic adds when it moves on)
-//   coder_bytes_kernel     one lane per pair: carries from the last byte to the first, the bytes, vpx_stop_encode's padding byte
+//                          byte position (a window in registers, collected in the wave's LDS, added to memory at the end)
+//   coder_bytes_kernel     one wave per pair: carries from the last byte to the first, the bytes, vpx_stop_encode's padding byte
 // The 32 "stop" decisions (bit 0, probability 128) are decisions n .. n+31 of a list.
 // A list entry is e = q << 1 | bit with q = the probability of the bit that occurred, in 1/256 (bit 0: the decision's probability p,
 // bit 1: 256 - p; written so by the resolve kernel).  With x = range - 1:  bit 0: what is left is split = (x p + 256) >> 8;  bit 1:

@@ -26,9 +26,7 @@
 //                         counters, write them back.  The counters live in a keyed LDS cache in front of a spill table in HBM.
 //                         Output: (probability of the bit that occurred, bit) appended to the list of the decision's tag.
 //                                                                                                  (serial per stream, 512 wide)
-//   coder_range_kernel    one lane per (stream, tag): the bool coder's range recurrence over that tag's list       (serial per tag)
-//   coder_accum_kernel, coder_bytes_kernel   the bool coder's `low`: addends summed per output byte position by chunks of the list,
-//                         then the carries and the bytes                                                            (parallel)
+//   (the bool coder behind them - range walk, sums, carries - is lh264_coder.hip's, shared by both forms)
 //
 // Halving is lazy: the table holds the un-halved pair of counters and the reader halves when their sum has passed 512, so the
 // probability always follows from the pair; zero-filled memory is the initial state.  See DESIGN.md section 4.3.
