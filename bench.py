@@ -307,6 +307,9 @@ def main():
     # wave beside them.  Enqueued behind the coder's first half, whichever of the two reached a CU first kept it, and a change as small
     # as a fill kernel more or less moved the step between 26.6 and 34.5 ms (LH264_BENCH_RECON_FIRST=0: that order, for comparison)
     recon_first = os.environ.get("LH264_BENCH_RECON_FIRST", "1") == "1"
+    # (experiment, measured and not adopted: the next batch's context indices enqueued at the top of the step instead of behind this
+    # batch's binarisation - they then compete with the count / emit kernels the host waits for: 31.1 against 25.9 ms a step)
+    ctx_early = os.environ.get("LH264_BENCH_CTX_EARLY", "0") == "1"
 
     def recon_on_side():
         with torch.cuda.stream(side):
@@ -344,14 +347,19 @@ def main():
         cur.wait_event(ctx_done[i])                 # batch i's context indices (row a8), computed during the step before
         if recon_first:
             recon_on_side()                         # rows a1-a7
+        if ctx_early:
+            with torch.cuda.stream(third):
+                ctxs[j].run()
+                ctx_done[j].record(third)
         coders[i].binarise()                        # rows a9/a10, first half, batch i
         ev_binarised.record(cur)
         if not recon_first:
             recon_on_side()
-        third.wait_event(ev_binarised)
-        with torch.cuda.stream(third):
-            ctxs[j].run()                           # row a8 of the next batch
-            ctx_done[j].record(third)
+        if not ctx_early:
+            third.wait_event(ev_binarised)
+            with torch.cuda.stream(third):
+                ctxs[j].run()                       # row a8 of the next batch
+                ctx_done[j].record(third)
         coders[i].finish()                          # rows a9/a10, second half, batch i
         cur.wait_stream(side)
 
