@@ -310,6 +310,9 @@ def main():
     # (experiment, measured and not adopted: the next batch's context indices enqueued at the top of the step instead of behind this
     # batch's binarisation - they then compete with the count / emit kernels the host waits for: 31.1 against 25.9 ms a step)
     ctx_early = os.environ.get("LH264_BENCH_CTX_EARLY", "0") == "1"
+    # (experiment, measured and not adopted: the reconstruct chain and the coder chain not joined at the ends of a step - 32.4 against
+    # 25.6 ms a step on the bench batch, the same on the CIF batch, 187 against 198 ms on the 720p batch)
+    free_run = os.environ.get("LH264_BENCH_FREE_RUN", "0") == "1"
 
     def recon_on_side():
         with torch.cuda.stream(side):
@@ -331,7 +334,8 @@ def main():
             coder.run()
             ev[3].record()
             return
-        side.wait_stream(cur)   # (the end of the step before)
+        if not (free_run and state["pipelined"]):
+            side.wait_stream(cur)   # (the end of the step before)
         if not state["pipelined"]:
             if recon_first:
                 recon_on_side()
@@ -361,7 +365,8 @@ def main():
                 ctxs[j].run()                       # row a8 of the next batch
                 ctx_done[j].record(third)
         coders[i].finish()                          # rows a9/a10, second half, batch i
-        cur.wait_stream(side)
+        if not free_run:
+            cur.wait_stream(side)
 
     step(timed=True)            # untimed priming pass on one stream: the coder's work memory is allocated here, not beside the first kernel
     torch.cuda.synchronize(dev)
